@@ -1,0 +1,44 @@
+"""Centered clipping (reference ``fllib/aggregators/centeredclipping.py``)."""
+from typing import Optional
+
+import torch
+
+from blades_amd import ops
+from .base import Aggregator
+
+
+class Centeredclipping(Aggregator):
+    r"""``n_iter`` times: ``m <- m + (1/K) sum_i clip(x_i - m)`` with
+    ``clip(v) = v * min(1, tau/||v||)``; ``m`` (the "momentum") persists across
+    rounds and is naturally column-sharded.
+
+    Each iteration is one fused distance pass (+ ``[K]`` all-reduce) and one
+    weighted column sum: ``m' = (1 - S/K) m + (1/K) sum_i s_i x_i`` with
+    ``s_i = min(1, tau/||x_i - m||)``, ``S = sum s_i`` — no per-client host sync.
+    """
+
+    def __init__(self, tau: Optional[float] = 5.0, n_iter: Optional[int] = 5):
+        super().__init__()
+        self.tau = tau
+        self.n_iter = n_iter
+        self.momentum = None
+
+    def aggregate(self, U, ctx):
+        K = U.shape[0]
+        if self.momentum is None or self.momentum.shape[0] != U.shape[1]:
+            self.momentum = torch.zeros(U.shape[1], device=U.device, dtype=torch.float32)
+        m = self.momentum.to(U.device)
+        for _ in range(self.n_iter):
+            d2 = ops.sqdist_to(U, m)
+            if ctx.distributed:
+                ctx.all_reduce(d2)
+            s = (self.tau / d2.sqrt()).clamp(max=1.0)  # tau/0 = inf -> 1
+            m = m * (1.0 - s.sum() / K) + ops.weighted_col_sum(U, s / K)
+        self.momentum = m
+        return m.clone()
+
+    def state_dict(self):
+        return {"momentum": None if self.momentum is None else self.momentum.detach().cpu()}
+
+    def load_state_dict(self, state):
+        self.momentum = state.get("momentum")

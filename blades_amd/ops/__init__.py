@@ -1,0 +1,172 @@
+"""Update-matrix primitives: HIP kernels on the GPU, torch oracle on the CPU.
+
+There is exactly one GPU implementation of every primitive — the hand-written
+gfx950 kernel in ``csrc/`` loaded through ``_hip`` — and no silent fallback:
+calling a primitive with a GPU tensor while ``libblades_hip.so`` is missing
+raises.  CPU tensors run ``reference.py`` (the numerical contract the kernels
+are tested against), which is what keeps the whole framework runnable and
+testable on a machine without a GPU.
+"""
+import torch
+
+from . import reference as ref
+
+_FORCE_REFERENCE = False  # tests flip this to compare kernel vs oracle on GPU
+
+
+def _use_hip(t: torch.Tensor) -> bool:
+    return t.is_cuda and not _FORCE_REFERENCE
+
+
+def _hip():
+    from . import _hip as h  # noqa: WPS433 (lazy: ctypes load)
+
+    return h
+
+
+class force_reference:
+    """Context manager: run the torch oracle even for GPU tensors."""
+
+    def __enter__(self):
+        global _FORCE_REFERENCE
+        self._old = _FORCE_REFERENCE
+        _FORCE_REFERENCE = True
+
+    def __exit__(self, *a):
+        global _FORCE_REFERENCE
+        _FORCE_REFERENCE = self._old
+
+
+def _f32c(U):
+    assert U.dtype == torch.float32 and U.dim() == 2, "update matrix must be [K, D] fp32"
+    assert U.stride(1) == 1, "update matrix rows must be contiguous"
+    return U
+
+
+def weighted_col_sum(U, w):
+    if _use_hip(_f32c(U)):
+        return _hip().weighted_col_sum(U, w)
+    return ref.weighted_col_sum(U, w)
+
+
+def col_mean(U, mask=None):
+    if _use_hip(_f32c(U)):
+        K = U.shape[0]
+        if mask is None:
+            w = torch.full((K,), 1.0 / K, device=U.device, dtype=torch.float32)
+        else:
+            m = mask.to(device=U.device, dtype=torch.float32)
+            w = m / m.sum()
+        return _hip().weighted_col_sum(U, w)
+    return ref.col_mean(U, mask)
+
+
+def col_mean_std(U, mask=None):
+    if _use_hip(_f32c(U)):
+        return _hip().col_mean_std(U, mask)
+    return ref.col_mean_std(U, mask)
+
+
+def col_min_max(U, mask=None):
+    if _use_hip(_f32c(U)):
+        return _hip().col_min_max(U, mask)
+    return ref.col_min_max(U, mask)
+
+
+def col_median(U, mask=None):
+    if _use_hip(_f32c(U)):
+        return _hip().col_order_stat(U, mask, 0, 0)
+    return ref.col_median(U, mask)
+
+
+def col_trimmed_mean(U, b, mask=None):
+    n = U.shape[0] if mask is None else int((mask != 0).sum())
+    if n <= 2 * b:
+        raise ValueError("Not enough inputs to compute trimmed mean")
+    if _use_hip(_f32c(U)):
+        return _hip().col_order_stat(U, mask, 1, int(b))
+    return ref.col_trimmed_mean(U, b, mask)
+
+
+def row_stats(U, valid_cols=None):
+    if _use_hip(_f32c(U)):
+        return _hip().row_stats(U, U.shape[1] if valid_cols is None else int(valid_cols))
+    return ref.row_stats(U, valid_cols)
+
+
+def row_sqnorm(U):
+    if _use_hip(_f32c(U)):
+        return _hip().row_stats(U, U.shape[1], counts=False)[0]
+    return ref.row_sqnorm(U)
+
+
+def sqdist_to(U, m):
+    if _use_hip(_f32c(U)):
+        return _hip().sqdist_to(U, m)
+    return ref.sqdist_to(U, m)
+
+
+def gram(U):
+    if _use_hip(_f32c(U)):
+        return _hip().gram(U)
+    return ref.gram(U)
+
+
+def row_scale_(U, s):
+    if _use_hip(_f32c(U)):
+        return _hip().row_scale_(U, s)
+    return ref.row_scale_(U, s)
+
+
+def set_rows_(U, rows, v):
+    if _use_hip(_f32c(U)) and v.dim() == 1:
+        return _hip().set_rows_(U, rows, v)
+    return ref.set_rows_(U, rows, v)
+
+
+def alie_forge_(U, benign_mask, mal_rows, z, sign=None):
+    if _use_hip(_f32c(U)):
+        return _hip().alie_forge_(U, benign_mask, mal_rows, float(z), sign)
+    return ref.alie_forge_(U, benign_mask, mal_rows, z, sign)
+
+
+def ipm_forge_(U, benign_mask, mal_rows, scale):
+    if _use_hip(_f32c(U)):
+        return _hip().ipm_forge_(U, benign_mask, mal_rows, float(scale))
+    return ref.ipm_forge_(U, benign_mask, mal_rows, scale)
+
+
+def server_step_(theta, buf, agg, lr, momentum, first):
+    if theta.is_cuda and not _FORCE_REFERENCE:
+        return _hip().server_step_(theta, buf, agg, float(lr), float(momentum), bool(first))
+    return ref.server_step_(theta, buf, agg, lr, momentum, first)
+
+
+def client_sgd_step_(W, G, M, lr, momentum, first, gscale=None):
+    if W.is_cuda and not _FORCE_REFERENCE:
+        return _hip().client_sgd_step_(W, G, M, float(lr), float(momentum), bool(first), gscale)
+    return ref.client_sgd_step_(W, G, M, lr, momentum, first, gscale)
+
+
+def philox_uniform(n, seed, stream, offset=0, device="cpu"):
+    if torch.device(device).type == "cuda" and not _FORCE_REFERENCE:
+        return _hip().philox_uniform(n, seed, stream, offset, device)
+    return ref.philox_uniform(n, seed, stream, offset, device)
+
+
+def philox_normal(n, seed, stream, offset=0, mean=0.0, std=1.0, device="cpu"):
+    if torch.device(device).type == "cuda" and not _FORCE_REFERENCE:
+        return _hip().philox_normal(n, seed, stream, offset, mean, std, device)
+    return ref.philox_normal(n, seed, stream, offset, mean, std, device)
+
+
+def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite):
+    if _use_hip(_f32c(U)):
+        return _hip().add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite)
+    return ref.add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite)
+
+
+def power_iteration_top(G, iters=100):
+    if G.is_cuda and not _FORCE_REFERENCE:
+        return _hip().power_iteration_top(G, iters)
+    return ref.power_iteration_top(G, iters)

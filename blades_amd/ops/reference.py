@@ -1,0 +1,247 @@
+"""Plain-PyTorch fp32 reference ("oracle") of every update-matrix primitive.
+
+Each function here defines the numerical contract of the HIP kernel with the
+same name in ``csrc/`` (see ``blades_amd/ops/__init__.py`` for the dispatch).
+They run on any device; on CPU they are what the non-GPU test tier executes,
+and on the GPU test tier they are what each kernel is compared against.
+
+``U`` is always the ``[K, Dl]`` fp32 update matrix (row = client, column =
+parameter coordinate; ``Dl`` is the local column shard).  ``mask`` is an
+optional ``[K]`` tensor; rows with ``mask == 0`` do not take part.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+
+def _maskf(U, mask):
+    if mask is None:
+        return None
+    return mask.to(device=U.device, dtype=torch.float32)
+
+
+def weighted_col_sum(U: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``out[j] = sum_i w[i] * U[i, j]``."""
+    return torch.mv(U.t(), w.to(U.dtype))
+
+
+def col_mean(U: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if mask is None:
+        return U.mean(dim=0)
+    m = _maskf(U, mask)
+    return weighted_col_sum(U, m / m.sum())
+
+
+def col_mean_std(U, mask=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Column mean and *unbiased* std over the selected rows
+    (``torch.std`` default, reference ``alie_adversary.py:29-30``)."""
+    if mask is not None:
+        U = U[_maskf(U, mask) > 0]
+    return U.mean(dim=0), U.std(dim=0)
+
+
+def col_min_max(U, mask=None):
+    if mask is not None:
+        U = U[_maskf(U, mask) > 0]
+    return U.min(dim=0).values, U.max(dim=0).values
+
+
+def col_median(U, mask=None) -> torch.Tensor:
+    """Mean of lower and upper median (reference ``aggregators.py:12-16``)."""
+    if mask is not None:
+        U = U[_maskf(U, mask) > 0]
+    upper = U.median(dim=0).values
+    lower = (-U).median(dim=0).values
+    return (upper - lower) / 2
+
+
+def col_trimmed_mean(U, b: int, mask=None) -> torch.Tensor:
+    """Mean after dropping the ``b`` largest and ``b`` smallest per column
+    (reference ``aggregators.py:40-48``)."""
+    if mask is not None:
+        U = U[_maskf(U, mask) > 0]
+    n = U.shape[0]
+    if n <= 2 * b:
+        raise ValueError("Not enough inputs to compute trimmed mean")
+    if b == 0:
+        return U.mean(dim=0)
+    s = torch.sort(U, dim=0).values
+    return s[b: n - b].sum(dim=0) / (n - 2 * b)
+
+
+def row_stats(U: torch.Tensor, valid_cols: Optional[int] = None):
+    """Per-row ``(sum of squares [K] f32, counts [K,3] i64 of >0, <0, ==0)``
+    over the first ``valid_cols`` columns (the rest is shard padding)."""
+    if valid_cols is not None and valid_cols < U.shape[1]:
+        U = U[:, :valid_cols]
+    sq = (U * U).sum(dim=1)
+    pos = (U > 0).sum(dim=1)
+    neg = (U < 0).sum(dim=1)
+    zero = (U == 0).sum(dim=1)
+    return sq, torch.stack([pos, neg, zero], dim=1).to(torch.int64)
+
+
+def row_sqnorm(U):
+    return (U * U).sum(dim=1)
+
+
+def sqdist_to(U: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
+    """``out[i] = sum_j (U[i,j] - m[j])^2`` (partial over the local columns)."""
+    d = U - m.unsqueeze(0)
+    return (d * d).sum(dim=1)
+
+
+def gram(U: torch.Tensor) -> torch.Tensor:
+    """``U @ U.T`` in fp32 (partial over the local columns)."""
+    return U @ U.t()
+
+
+def row_scale_(U: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """In-place ``U[i, :] *= s[i]``."""
+    U.mul_(s.to(U.dtype).unsqueeze(1))
+    return U
+
+
+def set_rows_(U: torch.Tensor, rows: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """In-place ``U[rows[r], :] = v`` (``v`` is ``[Dl]`` or ``[len(rows), Dl]``)."""
+    U[rows] = v
+    return U
+
+
+def alie_forge_(U, benign_mask, mal_rows, z: float, sign: Optional[torch.Tensor] = None):
+    """Fused ALIE: ``v = mean + z * std * sign`` over benign rows, written
+    into every row of ``mal_rows``; returns ``v``."""
+    mean, std = col_mean_std(U, benign_mask)
+    if sign is not None:
+        std = std * sign
+    v = mean + z * std
+    if mal_rows.numel():
+        U[mal_rows] = v
+    return v
+
+
+def ipm_forge_(U, benign_mask, mal_rows, scale: float):
+    v = -scale * col_mean(U, benign_mask)
+    if mal_rows.numel():
+        U[mal_rows] = v
+    return v
+
+
+def server_step_(theta, buf, agg, lr: float, momentum: float, first: bool):
+    """Fused server SGD on a flat slice (reference ``server.py:109-130``):
+    ``g = -agg; buf = g if first else momentum*buf + g; theta -= lr*buf``
+    (``torch.optim.SGD`` with dampening 0, no nesterov, no weight decay)."""
+    if momentum != 0.0:
+        if first:
+            buf.copy_(agg).neg_()
+        else:
+            buf.mul_(momentum).sub_(agg)
+        theta.sub_(buf, alpha=lr)
+    else:
+        theta.add_(agg, alpha=lr)
+    return theta
+
+
+def client_sgd_step_(W, G, M, lr: float, momentum: float, first: bool,
+                     gscale: Optional[torch.Tensor] = None):
+    """Fused per-client SGD on the replica matrix ``W[Kc, D]``.
+
+    ``g = G * gscale[row]`` (sign flip / clip coefficient), momentum buffer
+    ``M`` as ``torch.optim.SGD``; ``W -= lr * g``."""
+    g = G if gscale is None else G * gscale.unsqueeze(1)
+    if momentum != 0.0:
+        if first:
+            M.copy_(g)
+        else:
+            M.mul_(momentum).add_(g)
+        W.sub_(M, alpha=lr)
+    else:
+        W.sub_(g, alpha=lr)
+    return W
+
+
+# ---------------------------------------------------------------------------
+# Counter-based RNG (Philox4x32-10).  Values depend only on (seed, stream,
+# global element index), so a sharded run draws exactly the numbers a
+# single-GPU run draws for the same coordinates.
+# ---------------------------------------------------------------------------
+_M0, _M1 = 0xD2511F53, 0xCD9E8D57
+_W0, _W1 = 0x9E3779B9, 0xBB67AE85
+_MASK = 0xFFFFFFFF
+
+
+def _philox4x32(c0, c1, c2, c3, k0: int, k1: int):
+    """Vectorised Philox4x32-10 on int64 tensors holding uint32 values."""
+    for _ in range(10):
+        p0 = c0 * _M0
+        p1 = c2 * _M1
+        hi0, lo0 = (p0 >> 32) & _MASK, p0 & _MASK
+        hi1, lo1 = (p1 >> 32) & _MASK, p1 & _MASK
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & _MASK, lo1, (hi0 ^ c3 ^ k1) & _MASK, lo0
+        k0 = (k0 + _W0) & _MASK
+        k1 = (k1 + _W1) & _MASK
+    return c0, c1, c2, c3
+
+
+def philox_uniform(n: int, seed: int, stream: int, offset: int = 0, device="cpu"):
+    """``n`` uniforms in [0,1): element ``e = offset + i`` uses counter
+    ``(e//4 lo, e//4 hi, stream, 0)``, lane ``e % 4``, key from ``seed``;
+    ``u = (x >> 8) * 2^-24``."""
+    e = torch.arange(offset, offset + n, dtype=torch.int64, device=device)
+    blk = e >> 2
+    c0, c1 = blk & _MASK, (blk >> 32) & _MASK
+    c2 = torch.full_like(c0, stream & _MASK)
+    c3 = torch.zeros_like(c0)
+    r = _philox4x32(c0, c1, c2, c3, seed & _MASK, (seed >> 32) & _MASK)
+    lane = e & 3
+    x = torch.where(lane == 0, r[0], torch.where(lane == 1, r[1], torch.where(lane == 2, r[2], r[3])))
+    return ((x >> 8).to(torch.float32)) * (1.0 / 16777216.0)
+
+
+def philox_normal(n: int, seed: int, stream: int, offset: int = 0, mean=0.0, std=1.0, device="cpu"):
+    """Box–Muller on Philox words: element ``e`` uses counter ``(e//2, stream, 1)``
+    words (0,1) for even ``e`` (cos branch) and (2,3) for odd ``e`` (sin of the
+    second pair) — every element is an independent draw."""
+    e = torch.arange(offset, offset + n, dtype=torch.int64, device=device)
+    blk = e >> 1
+    c0, c1 = blk & _MASK, (blk >> 32) & _MASK
+    c2 = torch.full_like(c0, stream & _MASK)
+    c3 = torch.ones_like(c0)
+    r = _philox4x32(c0, c1, c2, c3, seed & _MASK, (seed >> 32) & _MASK)
+    odd = (e & 1).bool()
+    a = torch.where(odd, r[2], r[0])
+    b = torch.where(odd, r[3], r[1])
+    u1 = ((a >> 8).to(torch.float32) + 1.0) * (1.0 / 16777216.0)  # (0,1]
+    u2 = (b >> 8).to(torch.float32) * (1.0 / 16777216.0)
+    rad = torch.sqrt(-2.0 * torch.log(u1))
+    z = rad * torch.cos(6.283185307179586 * u2)
+    return z * std + mean
+
+
+def add_normal_rows_(U, rows, seed: int, stream: int, col_offset: int, d_total: int,
+                     mean: float, std: float, overwrite: bool):
+    """Rows ``rows[r]`` of ``U`` get (``overwrite``) or are incremented by
+    N(mean,std) noise; element ``(global_row_id g, global column c)`` uses the
+    Philox index ``g * d_total + c`` so the draw is shard-independent.
+    ``rows`` is ``[R,2]`` int64: (local row, global row id)."""
+    Dl = U.shape[1]
+    for lr_, g in rows.tolist():
+        z = philox_normal(Dl, seed, stream, offset=g * d_total + col_offset, mean=mean, std=std,
+                          device=U.device)
+        if overwrite:
+            U[lr_] = z
+        else:
+            U[lr_] += z
+    return U
+
+
+def power_iteration_top(G: torch.Tensor, iters: int = 100) -> torch.Tensor:
+    """Top eigenvector of a symmetric PSD ``[K,K]`` matrix by power iteration
+    from the all-ones/sqrt(K) start (deterministic)."""
+    K = G.shape[0]
+    v = torch.full((K,), 1.0 / K ** 0.5, dtype=G.dtype, device=G.device)
+    v = v + torch.arange(K, device=G.device, dtype=G.dtype) * (1e-3 / K)
+    for _ in range(iters):
+        w = G @ v
+        v = w / w.norm().clamp_min(1e-30)
+    return v
