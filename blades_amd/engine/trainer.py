@@ -1,0 +1,401 @@
+"""ClientEngine: trains all clients of a rank and produces the update matrix.
+
+Replaces the reference's hot loop — one Ray RPC and one sequential
+forward/backward per client (``blades/algorithms/fedavg/fedavg.py:203-224``,
+``fllib/clients/client.py:46-74``) — with batched execution:
+
+* **FedSGD path** (``num_batch_per_round == 1``, every shipped "fedsgd/fedavg"
+  YAML): all clients start from the same weights, so one vectorised
+  forward/backward over ``[Kc, B, …]`` with *shared* parameters yields the
+  per-client gradients; the update row is ``-lr * g`` (momentum buffer and
+  sign/clip coefficients fused in).  No per-client weight copies exist.
+* **General path** (``num_batch_per_round > 1``): per-client weight replicas
+  ``W[Kc, D]`` live in HBM for the duration of a chunk; every local step is a
+  vectorised forward/backward with *per-client* parameters followed by the
+  fused ``client_sgd_step_`` kernel; the update row is ``W_c - theta``.
+* **Sequential path**: reference semantics through ``Client.train_one_round``
+  for clients whose callbacks have Python-only behaviour.
+
+BatchNorm layers use batch statistics (``track_running_stats=False``); under
+vectorisation the statistics are per (client, channel), as they must be.
+
+Afterwards the row shard ``[K_r, Dpad]`` is re-laid-out into the column shard
+``[K, Dl]`` with one RCCL all-to-all (identity when ``world_size == 1``).
+"""
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.func import functional_call, grad_and_value, vmap
+
+from blades_amd import ops
+from blades_amd.constants import CLIENT_UPDATE
+from blades_amd.parallel.context import ShardContext, padded_width
+from .plan import RowPlan, make_plan
+from .sampler import DeviceSampler
+
+
+def _autocast(device: torch.device, dtype: Optional[torch.dtype]):
+    if dtype is None or dtype == torch.float32:
+        return torch.autocast(device_type=device.type, enabled=False)
+    return torch.autocast(device_type=device.type, dtype=dtype)
+
+
+_DTYPES = {None: None, "fp32": None, "float32": None, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+           "fp16": torch.float16, "float16": torch.float16}
+
+
+class ClientEngine:
+    def __init__(self, *, task, dataset, clients: list, runtime, client_lr: float, client_momentum: float,
+                 num_batch_per_round: int, batch_size: int, seed: int = 0, clients_per_chunk: int = 64,
+                 amp_dtype="auto", execution_mode: str = "auto", num_classes: Optional[int] = None,
+                 eval_clients_per_chunk: Optional[int] = None):
+        self.task = task
+        self.model = task.model
+        self.dataset = dataset
+        self.clients = clients
+        self.rt = runtime
+        self.device = runtime.device
+        self.lr = float(client_lr)
+        self.momentum = float(client_momentum)
+        self.nb = int(num_batch_per_round)
+        self.B = int(batch_size)
+        self.seed = int(seed)
+        self.chunk = max(1, int(clients_per_chunk))
+        self.eval_chunk = eval_clients_per_chunk or self.chunk
+        self.num_classes = num_classes
+        self.mode = execution_mode
+        if amp_dtype == "auto":
+            amp_dtype = "bf16" if self.device.type == "cuda" else None
+        self.amp_dtype = _DTYPES[amp_dtype] if not isinstance(amp_dtype, torch.dtype) else amp_dtype
+        self.timers: Dict[str, float] = {}
+        self.round = 0
+
+        # ---- parameter layout (named_parameters order == reference flattening)
+        self.names = [n for n, _ in self.model.named_parameters()]
+        self.shapes = [tuple(p.shape) for _, p in self.model.named_parameters()]
+        self.numels = [int(np.prod(s)) if len(s) else 1 for s in self.shapes]
+        self.offsets = np.concatenate([[0], np.cumsum(self.numels)]).astype(np.int64)
+        self.D = int(self.offsets[-1])
+        G = runtime.world_size
+        self.Dl = padded_width(self.D, G) if G > 1 else self.D
+        self.Dpad = self.Dl * G
+        self.ctx = ShardContext(d_total=self.D, world_size=G, rank=runtime.rank)
+
+        # ---- plan rows, collect per-client fused specs
+        self.K = len(clients)
+        trains = [bool(getattr(c, "local_training", True)) for c in clients]
+        self.plan: RowPlan = make_plan(trains, G)
+        self.local_ids = self.plan.local_clients(runtime.rank)
+        self.Kloc = len(self.local_ids)
+        self.refresh_client_specs()
+
+        # ---- resident data
+        ids = [clients[i].client_id for i in self.local_ids]
+        self._train_rows = np.array([r for r, i in enumerate(self.local_ids) if self._trains[r]], dtype=np.int64)
+        train_ids = [ids[r] for r in self._train_rows]
+        self.train_store = dataset.device_store(train_ids, self.device, "train")
+        self.sampler = DeviceSampler(self.train_store.lengths, self.train_store.offsets, self.B, self.device,
+                                     seed=self.seed * 7919 + runtime.rank)
+        self.test_store = dataset.device_store(ids, self.device, "test")
+        self.aug_gen = torch.Generator()
+        self.aug_gen.manual_seed(self.seed * 104729 + runtime.rank)
+
+        # ---- persistent buffers
+        self.U_row = torch.zeros(self.Kloc, self.Dpad, dtype=torch.float32, device=self.device)
+        self.U_col = self.U_row if G == 1 else torch.zeros(self.K, self.Dl, dtype=torch.float32,
+                                                            device=self.device)
+        self.M = None  # per-client momentum buffers [Kloc_train, D], lazily
+        self._mom_init = False
+
+    # ------------------------------------------------------------------
+    def refresh_client_specs(self):
+        """(Re)reads each local client's callbacks -> fused per-row settings."""
+        specs, trains = [], []
+        for i in self.local_ids:
+            c = self.clients[i]
+            trains.append(bool(getattr(c, "local_training", True)))
+            cbs = c.active_callbacks() if hasattr(c, "active_callbacks") else getattr(c, "callbacks", None)
+            spec = cbs.batched_spec() if cbs is not None and hasattr(cbs, "batched_spec") else {}
+            if self.mode == "sequential":
+                spec = None
+            specs.append(spec)
+        self._specs, self._trains = specs, trains
+        self._malicious = [bool(getattr(self.clients[i], "is_malicious", False)) for i in self.local_ids]
+
+    def _row_vectors(self, rows: np.ndarray):
+        """Per-row fused settings for local rows ``rows`` (all batched)."""
+        sp = [self._specs[r] for r in rows]
+        gscale = torch.tensor([s.get("grad_scale", 1.0) for s in sp], device=self.device)
+        flip = torch.tensor([s.get("label_flip", 0) for s in sp], device=self.device)
+        gclip = torch.tensor([s.get("grad_clip", float("inf")) for s in sp], device=self.device)
+        return gscale, flip, gclip
+
+    # ------------------------------------------------------------------
+    def _params_from_flat(self, flat: torch.Tensor, batched: bool = False) -> Dict[str, torch.Tensor]:
+        out = {}
+        for n, s, o, m in zip(self.names, self.shapes, self.offsets[:-1], self.numels):
+            v = flat[..., int(o): int(o) + m]
+            out[n] = v.reshape(*flat.shape[:-1], *s) if batched else v.reshape(s)
+        return out
+
+    def _client_loss(self, params, x, y):
+        def m(inp):
+            return functional_call(self.model, params, (inp,))
+
+        with _autocast(self.device, self.amp_dtype):
+            return self.task.loss(m, x, y)
+
+    def _grads(self, params, X, Y, per_client_params: bool):
+        """Vectorised per-client (grads dict [Kc,…], losses [Kc])."""
+        fn = vmap(grad_and_value(self._client_loss), in_dims=(0 if per_client_params else None, 0, 0),
+                  randomness="different")
+        return fn(params, X, Y)
+
+    def _fetch_batch(self, srows: np.ndarray, flip: torch.Tensor):
+        """One training batch per client of sampler rows ``srows`` -> X[Kc,B,…], Y[Kc,B]."""
+        idx = self.sampler.next_indices(srows)
+        Kc = len(srows)
+        X = self.train_store.x[idx.reshape(-1)].reshape(Kc, self.B, *self.train_store.x.shape[1:])
+        Y = self.train_store.y[idx.reshape(-1)].reshape(Kc, self.B)
+        tf = self.dataset.train_transform
+        if tf is not None:
+            if hasattr(tf, "draw"):
+                X = tf.apply(X, tf.draw(Kc, self.aug_gen, X.shape[-2], X.shape[-1]))
+            else:
+                X = torch.stack([tf(X[c]) for c in range(Kc)])
+        if bool((flip > 0).any()):
+            Y = torch.where(flip.unsqueeze(1) > 0, flip.unsqueeze(1) - 1 - Y, Y)
+        return X, Y
+
+    @staticmethod
+    def _clip_coef(sqnorm: torch.Tensor, thr: torch.Tensor) -> torch.Tensor:
+        return (thr / (sqnorm.sqrt() + 1e-6)).clamp(max=1.0)
+
+    def _flatten_into(self, grads: Dict[str, torch.Tensor], out: torch.Tensor):
+        Kc = out.shape[0]
+        for n, o, m in zip(self.names, self.offsets[:-1], self.numels):
+            out[:, int(o): int(o) + m].copy_(grads[n].reshape(Kc, m))
+
+    # ------------------------------------------------------------------
+    def _train_chunk_fedsgd(self, theta, rows, srows):
+        gscale, flip, gclip = self._row_vectors(rows)
+        X, Y = self._fetch_batch(srows, flip)
+        grads, losses = self._grads(self._params_from_flat(theta), X, Y, per_client_params=False)
+        G = torch.empty(len(rows), self.D, device=self.device)
+        self._flatten_into(grads, G)
+        del grads
+        if bool(torch.isfinite(gclip).any()):
+            gscale = gscale * self._clip_coef(ops.row_sqnorm(G), gclip)
+        rows_t = torch.as_tensor(rows, device=self.device)
+        if self.momentum != 0.0:
+            if self.M is None:
+                self.M = torch.zeros(len(self._train_rows), self.D, device=self.device)
+            srows_t = torch.as_tensor(srows, device=self.device)
+            Mv = self.M[srows_t]
+            W = torch.zeros_like(G)  # W - 0 = update after one fused step from zero
+            ops.client_sgd_step_(W, G, Mv, self.lr, self.momentum, not self._mom_init, gscale)
+            self.M[srows_t] = Mv
+            G = W
+        else:
+            ops.row_scale_(G, -self.lr * gscale)
+        self.U_row[rows_t, : self.D] = G
+        return losses
+
+    def _train_chunk_general(self, theta, rows, srows):
+        gscale0, flip, gclip = self._row_vectors(rows)
+        Kc = len(rows)
+        W = theta.unsqueeze(0).expand(Kc, self.D).contiguous()
+        G = torch.empty_like(W)
+        srows_t = torch.as_tensor(srows, device=self.device)
+        if self.momentum != 0.0:
+            if self.M is None:
+                self.M = torch.zeros(len(self._train_rows), self.D, device=self.device)
+            Mv = self.M[srows_t].contiguous()
+        else:
+            Mv = W  # unused
+        loss_acc = torch.zeros(Kc, device=self.device)
+        for step in range(self.nb):
+            X, Y = self._fetch_batch(srows, flip)
+            grads, losses = self._grads(self._params_from_flat(W, batched=True), X, Y, per_client_params=True)
+            self._flatten_into(grads, G)
+            del grads
+            gs = gscale0
+            if bool(torch.isfinite(gclip).any()):
+                gs = gs * self._clip_coef(ops.row_sqnorm(G), gclip)
+            first = (not self._mom_init) and step == 0
+            ops.client_sgd_step_(W, G, Mv, self.lr, self.momentum, first, gs)
+            loss_acc += losses
+        if self.momentum != 0.0:
+            self.M[srows_t] = Mv
+        rows_t = torch.as_tensor(rows, device=self.device)
+        self.U_row[rows_t, : self.D] = W - theta.unsqueeze(0)
+        return loss_acc / self.nb
+
+    def _train_sequential(self, theta, r):
+        """Reference-semantics round for local row ``r`` (Python callbacks)."""
+        from blades_amd.parallel.worker import current_worker
+
+        client = self.clients[self.local_ids[r]]
+        w = current_worker()
+        with torch.no_grad():
+            torch.nn.utils.vector_to_parameters(theta.to(next(w.task.model.parameters()).device),
+                                                w.task.model.parameters())
+        res = client.train_one_round(self.dataset.get_train_loader(client.client_id))
+        upd = res.get(CLIENT_UPDATE)
+        if upd is not None:
+            self.U_row[r, : self.D] = upd.to(self.device)
+        return res.get("avg_loss", float("nan"))
+
+    # ------------------------------------------------------------------
+    def train_round(self, theta: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Returns (U_col [K, Dl], sum of benign losses, number of benign clients) —
+        the last two already reduced over ranks."""
+        t0 = time.perf_counter()
+        dev = self.device
+        theta = theta.detach()[: self.D]
+        self.model.train()
+        loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
+        loss_cnt = torch.zeros((), device=dev, dtype=torch.float64)
+        batched = [k for k, r in enumerate(self._train_rows) if self._specs[r] is not None]
+        seq = [k for k, r in enumerate(self._train_rows) if self._specs[r] is None]
+        nontrain = [r for r in range(self.Kloc) if not self._trains[r]]
+        if nontrain:
+            self.U_row[torch.as_tensor(nontrain, device=dev)] = 0
+        with torch.enable_grad():
+            for c0 in range(0, len(batched), self.chunk):
+                ks = np.array(batched[c0: c0 + self.chunk], dtype=np.int64)
+                rows = self._train_rows[ks]
+                if self.nb == 1:
+                    losses = self._train_chunk_fedsgd(theta, rows, ks)
+                else:
+                    losses = self._train_chunk_general(theta, rows, ks)
+                benign = torch.tensor([not self._malicious[r] for r in rows], device=dev)
+                loss_sum += (losses.double() * benign).sum()
+                loss_cnt += benign.sum()
+        for k in seq:
+            r = int(self._train_rows[k])
+            l = self._train_sequential(theta, r)
+            if not self._malicious[r]:
+                loss_sum += l
+                loss_cnt += 1
+        self._mom_init = True
+        self._post_round_hooks()
+        self.timers["local_train_s"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        U = self.exchange()
+        if self.ctx.distributed:
+            pack = torch.stack([loss_sum, loss_cnt])
+            self.ctx.all_reduce(pack)
+            loss_sum, loss_cnt = pack[0], pack[1]
+        self.timers["exchange_s"] = time.perf_counter() - t1
+        self.round += 1
+        return U, loss_sum, loss_cnt
+
+    def _post_round_hooks(self):
+        """Fused ``on_train_round_end`` effects: update clip + DP noise."""
+        rows = [r for r in self._train_rows if self._specs[r] and (
+            "update_clip" in self._specs[r] or self._specs[r].get("update_noise_std", 0) > 0)]
+        if not rows:
+            return
+        rt = torch.as_tensor(rows, device=self.device)
+        blk = self.U_row[rt][:, : self.D].contiguous()
+        clip = torch.tensor([self._specs[r].get("update_clip", float("inf")) for r in rows], device=self.device)
+        if bool(torch.isfinite(clip).any()):
+            ops.row_scale_(blk, self._clip_coef(ops.row_sqnorm(blk), clip))
+        stds = {self._specs[r].get("update_noise_std", 0.0) for r in rows}
+        for std in stds:
+            if std > 0:
+                sel = [k for k, r in enumerate(rows) if self._specs[r].get("update_noise_std", 0.0) == std]
+                pairs = torch.tensor([[k, self.local_ids[rows[k]]] for k in sel], dtype=torch.int64)
+                ops.add_normal_rows_(blk, pairs, self.seed, 1000 + self.round, 0, self.D, 0.0, std, False)
+        self.U_row[rt, : self.D] = blk
+
+    # ------------------------------------------------------------------
+    def exchange(self) -> torch.Tensor:
+        """Row shard -> column shard (all-to-all over RCCL / xGMI)."""
+        if not self.ctx.distributed:
+            return self.U_row
+        G = self.rt.world_size
+        send = self.U_row.view(self.Kloc, G, self.Dl).transpose(0, 1).contiguous()
+        rows = self.plan.rows_per_rank()
+        in_splits = [self.Kloc * self.Dl] * G
+        out_splits = [k * self.Dl for k in rows]
+        dist.all_to_all_single(self.U_col.view(-1), send.view(-1), out_splits, in_splits)
+        self.ctx.stats["alltoall_bytes"] = send.numel() * 4
+        return self.U_col
+
+    def gather_full(self) -> torch.Tensor:
+        """Explicit "all-gather the full update matrix" mode (BASELINE config #5):
+        every rank ends up with ``[K, D]``."""
+        if not self.ctx.distributed:
+            return self.U_row[:, : self.D]
+        rows = self.plan.rows_per_rank()
+        parts = [torch.empty(k, self.Dpad, device=self.device) for k in rows]
+        dist.all_gather(parts, self.U_row)
+        return torch.cat(parts, dim=0)[:, : self.D]
+
+    # -- masks in row order ------------------------------------------------
+    def row_mask(self, flags: List[bool]) -> torch.Tensor:
+        """[K] float mask in global row order from a per-client flag list."""
+        f = np.asarray(flags, dtype=np.float32)[self.plan.client_of_row]
+        return torch.from_numpy(f).to(self.device)
+
+    # ------------------------------------------------------------------
+    @torch.no_grad()
+    def evaluate(self, theta: torch.Tensor) -> Dict[str, float]:
+        """All clients' test shards (malicious ones too, like the reference),
+        batches of ``test_bs`` with batch-statistics BN; length-weighted means."""
+        theta = theta.detach()[: self.D]
+        self.model.eval()
+        params = self._params_from_flat(theta)
+        bs = self.dataset.test_bs
+        tf = self.dataset.test_transform
+        st = self.test_store
+        acc = torch.zeros(3, device=self.device, dtype=torch.float64)  # ce_sum, correct, n
+
+        def fwd(x):
+            with _autocast(self.device, self.amp_dtype):
+                return functional_call(self.model, params, (x,)).float()
+
+        vf = vmap(fwd, in_dims=0, randomness="different")
+        by_len: Dict[int, List[int]] = {}
+        for r, n in enumerate(st.lengths):
+            by_len.setdefault(int(n), []).append(r)
+        for n, rs in by_len.items():
+            if n == 0:
+                continue
+            for c0 in range(0, len(rs), self.eval_chunk):
+                rr = rs[c0: c0 + self.eval_chunk]
+                offs = torch.as_tensor(st.offsets[rr], device=self.device)
+                for b0 in range(0, n, bs):
+                    m = min(bs, n - b0)
+                    idx = (offs.unsqueeze(1) + torch.arange(b0, b0 + m, device=self.device).unsqueeze(0))
+                    X = st.x[idx.reshape(-1)].reshape(len(rr), m, *st.x.shape[1:])
+                    Y = st.y[idx.reshape(-1)].reshape(len(rr), m)
+                    if tf is not None:
+                        X = tf(X)
+                    logits = vf(X)
+                    ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), Y.reshape(-1),
+                                                           reduction="sum")
+                    correct = (logits.argmax(-1) == Y).sum()
+                    acc += torch.stack([ce.double(), correct.double(), torch.tensor(float(Y.numel()),
+                                                                                  device=self.device,
+                                                                                  dtype=torch.float64)])
+        self.ctx.all_reduce(acc)
+        ce, correct, n = acc.tolist()
+        return {"ce_loss": ce / max(n, 1.0), "acc_top_1": correct / max(n, 1.0), "num_test_samples": int(n)}
+
+    # -- checkpoint -------------------------------------------------------
+    def state_dict(self):
+        return {"sampler": self.sampler.state_dict(), "aug_gen": self.aug_gen.get_state(),
+                "M": None if self.M is None else self.M.cpu(), "mom_init": self._mom_init, "round": self.round}
+
+    def load_state_dict(self, s):
+        self.sampler.load_state_dict(s["sampler"])
+        self.aug_gen.set_state(s["aug_gen"])
+        self.M = None if s["M"] is None else s["M"].to(self.device)
+        self._mom_init = s["mom_init"]
+        self.round = s["round"]

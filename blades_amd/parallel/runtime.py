@@ -1,0 +1,88 @@
+"""Process runtime: one PyTorch-ROCm process per GPU, RCCL over xGMI.
+
+This replaces the reference's Ray actor layer (``fllib/core/execution``): ranks
+are launched with ``python -m torch.distributed.run`` (or
+``blades_amd.parallel.launcher``), read ``RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*``
+from the environment and join one process group — backend ``nccl`` (= RCCL on
+ROCm) when the rank owns a GPU, ``gloo`` otherwise (CPU tests).
+"""
+import datetime
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from blades_amd.constants import DEFAULT_MASTER_ADDR, DEFAULT_MASTER_PORT
+
+
+@dataclass
+class Runtime:
+    rank: int = 0
+    world_size: int = 1
+    local_rank: int = 0
+    device: torch.device = torch.device("cpu")
+    backend: Optional[str] = None
+    owns_group: bool = False
+
+    @property
+    def is_main(self) -> bool:
+        return self.rank == 0
+
+    @property
+    def distributed(self) -> bool:
+        return self.world_size > 1
+
+
+_runtime: Optional[Runtime] = None
+
+
+def init_runtime(use_gpu: Optional[bool] = None, timeout_s: int = 600) -> Runtime:
+    """Idempotent.  ``use_gpu=None`` -> GPU iff one is visible."""
+    global _runtime
+    if _runtime is not None:
+        return _runtime
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if use_gpu is None:
+        use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        ndev = torch.cuda.device_count()
+        device = torch.device("cuda", local_rank % max(ndev, 1))
+        torch.cuda.set_device(device)
+    else:
+        device = torch.device("cpu")
+    backend = None
+    owns = False
+    if world > 1:
+        backend = "nccl" if use_gpu else "gloo"
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", DEFAULT_MASTER_ADDR)
+            os.environ.setdefault("MASTER_PORT", DEFAULT_MASTER_PORT)
+            kwargs = {}
+            if use_gpu:
+                kwargs["device_id"] = device
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+            owns = True
+    _runtime = Runtime(rank, world, local_rank, device, backend, owns)
+    return _runtime
+
+
+def get_runtime() -> Runtime:
+    return _runtime if _runtime is not None else init_runtime()
+
+
+def set_runtime(rt: Optional[Runtime]) -> None:
+    """Override (tests / embedding in an existing process group)."""
+    global _runtime
+    _runtime = rt
+
+
+def shutdown_runtime() -> None:
+    global _runtime
+    if _runtime is not None and _runtime.owns_group and dist.is_initialized():
+        dist.destroy_process_group()
+    _runtime = None

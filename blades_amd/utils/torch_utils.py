@@ -1,0 +1,69 @@
+"""Tensor helpers (subset of ``fllib/utils/torch_utils.py`` that is in use)."""
+import os
+import random
+from typing import Iterable, Optional, Union
+
+import numpy as np
+import torch
+
+
+def set_torch_seed(seed: Optional[int]) -> None:
+    """Seeds python / numpy / torch (reference ``torch_utils.py:160-177``)."""
+    if seed is None:
+        return
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+
+
+def parameters_to_vector(parameters: Iterable[torch.Tensor]) -> torch.Tensor:
+    return torch.cat([p.reshape(-1) for p in parameters])
+
+
+def vector_to_parameters(vec: torch.Tensor, parameters: Iterable[torch.Tensor]) -> None:
+    pointer = 0
+    for p in parameters:
+        n = p.numel()
+        p.data.copy_(vec[pointer: pointer + n].view_as(p))
+        pointer += n
+
+
+def clip_tensor_norm_(tensor: torch.Tensor, max_norm: float, norm_type: float = 2.0,
+                      error_if_nonfinite: bool = False) -> torch.Tensor:
+    """In-place L2 clip of one tensor; returns the tensor.
+
+    (The reference version loops over a list and returns after the first
+    element — ``torch_utils.py:281-322`` — which is only right for a single
+    tensor, the only way it is called.)
+    """
+    total_norm = torch.linalg.vector_norm(tensor, norm_type)
+    if error_if_nonfinite and not torch.isfinite(total_norm):
+        raise RuntimeError("non-finite norm in clip_tensor_norm_")
+    coef = torch.clamp(max_norm / (total_norm + 1e-6), max=1.0)
+    tensor.mul_(coef.to(tensor.device))
+    return tensor
+
+
+def clip_para_norm_(parameters: Union[torch.Tensor, Iterable[torch.Tensor]], max_norm: float,
+                    norm_type: float = 2.0) -> torch.Tensor:
+    """In-place clip of the joint norm of parameter *values* (``:235-278``)."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    params = [p for p in parameters]
+    if not params:
+        return torch.tensor(0.0)
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.detach(), norm_type) for p in params]),
+                                     norm_type)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for p in params:
+        p.detach().mul_(coef.to(p.device))
+    return total
+
+
+def get_device(num_gpus: float = 0, index: int = 0) -> torch.device:
+    if num_gpus > 0 and torch.cuda.is_available():
+        return torch.device("cuda", index)
+    return torch.device("cpu")
