@@ -1,0 +1,189 @@
+"""Adaptive (Fang), MinMax, SignGuard-attack, ClippedClustering-attack."""
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+
+from blades_amd import ops
+from blades_amd.aggregators.base import global_gram, pairwise_sqdist_from_gram
+from blades_amd.aggregators.clippedclustering import cosine_distance_from_gram
+from blades_amd.ops import host
+from .adversary import Adversary
+from .simple import _is_signguard, half_negation_sign
+
+
+def _seed(cfg) -> int:
+    return int(getattr(cfg, "seed", 0) or 0)
+
+
+class AdaptiveAdversary(Adversary):
+    """Fang et al. attack on Median/TrimmedMean (``adaptive_adversary.py:22-67``).
+
+    With ``s = sign(mean)``, ``mx/mn`` the benign column max/min, ``b = 2`` and
+    ``u ~ U(0,1)`` per coordinate:
+
+    ====================  ==========================================
+    s = -1, mx > 0        ``mx * (1 + u (b-1))``
+    s = -1, mx < 0        ``mx * (1 + u (1/b - 1))``
+    s = +1, mn > 0        ``mn * (1/b + u (1 - 1/b))``
+    s = +1, mn < 0        ``mn * (b + u (1 - b))``
+    s = 0                 ``mean`` (= 0)
+    otherwise (mx|mn = 0)  0
+    ====================  ==========================================
+    """
+
+    def forge(self, algorithm, U, ctx):
+        mask = algorithm.benign_mask
+        mean = ops.col_mean(U, mask)
+        mn, mx = ops.col_min_max(U, mask)
+        b = 2.0
+        u = ops.philox_uniform(U.shape[1], _seed(self.global_config), 3000 + self._round, ctx.col_offset,
+                               device=U.device)
+        s = torch.sign(mean)
+        out = torch.zeros_like(mean)
+        out = torch.where((s == -1) & (mx > 0), mx * (1 + u * (b - 1)), out)
+        out = torch.where((s == -1) & (mx < 0), mx * (1 + u * (1 / b - 1)), out)
+        out = torch.where((s == 1) & (mn > 0), mn * (1 / b + u * (1 - 1 / b)), out)
+        out = torch.where((s == 1) & (mn < 0), mn * (b + u * (1 - b)), out)
+        out = torch.where(s == 0, mean, out)
+        ops.set_rows_(U, algorithm.malicious_rows, out)
+        return out
+
+
+class MinMaxAdversary(Adversary):
+    """Shejwalkar & Houmansadr "min-max": ``mean - gamma * std`` with the largest
+    ``gamma`` in [0,5] (bisection to 0.01) such that the forged vector's max
+    distance to a benign update stays below the max benign pairwise distance
+    (``minmax_adversary.py:37-63``).
+
+    The bisection needs no pass over D: with ``a_i = ||mean - x_i||^2``,
+    ``b_i = (mean - x_i) . dev`` and ``c = ||dev||^2`` the distance is
+    ``a_i - 2 gamma b_i + gamma^2 c``.  So the whole attack is one fused
+    mean/std pass, one Gram GEMM, two row reductions, and scalar math that
+    stays on the device.
+    """
+
+    def __init__(self, clients, global_config: Dict = None):
+        super().__init__(clients, global_config)
+        self.threshold = 3.0
+        self.threshold_diff = 1e-4
+        self.num_byzantine = None
+        self.negative_indices = None
+
+    def forge(self, algorithm, U, ctx):
+        mask = algorithm.benign_mask
+        bm = mask > 0
+        mean, dev = ops.col_mean_std(U, mask)
+        if _is_signguard(algorithm):
+            dev = dev * half_negation_sign(ctx, U.device)
+        G = global_gram(U, ctx)
+        d2 = pairwise_sqdist_from_gram(G)[bm][:, bm]
+        threshold = d2.max().sqrt()
+        a = ops.sqdist_to(U, mean)
+        b = ops.row_dot(U, dev)
+        scal = torch.stack([(mean * dev).sum(), (dev * dev).sum()])
+        if ctx.distributed:
+            ctx.all_reduce(a), ctx.all_reduce(b), ctx.all_reduce(scal)
+        a, b = a[bm], scal[0] - b[bm]
+        c = scal[1]
+        low = torch.zeros((), device=U.device)
+        high = torch.full((), 5.0, device=U.device)
+        mid = (low + high) / 2
+        lo_f, hi_f = 0.0, 5.0
+        while abs(hi_f - lo_f) > 0.01:  # fixed trip count: the interval halves every time
+            mid = (low + high) / 2
+            loss = (a - 2 * mid * b + mid * mid * c).clamp_min(0).max().sqrt()
+            ok = loss < threshold
+            low = torch.where(ok, mid, low)
+            high = torch.where(ok, high, mid)
+            hi_f = lo_f + (hi_f - lo_f) / 2
+        out = mean - mid * dev
+        ops.set_rows_(U, algorithm.malicious_rows, out)
+        self.num_byzantine = int(algorithm.malicious_rows.numel())
+        return out
+
+
+class SignGuardAdversary(Adversary):
+    """Noise with the benign mean's sign statistics (``signguard_adversary.py:39-67``):
+    a fraction pos/D of the coordinates gets ``+U(0,1)``, neg/D gets ``-U(0,1)``,
+    the rest 0, at random positions.
+
+    The reference builds the three blocks with exact counts and applies a CPU
+    ``randperm(D)``; here each coordinate draws its class independently with
+    those probabilities (counter-based RNG on the global coordinate index), which
+    matches the counts to O(sqrt(D)) and is shard-invariant."""
+
+    def forge(self, algorithm, U, ctx):
+        mean = ops.col_mean(U, algorithm.benign_mask)
+        valid = torch.arange(U.shape[1], device=U.device) < ctx.d_valid
+        cnt = torch.stack([((mean > 0) & valid).sum(), ((mean < 0) & valid).sum()]).double()
+        if ctx.distributed:
+            ctx.all_reduce(cnt)
+        p_pos, p_neg = cnt[0] / ctx.d_total, cnt[1] / ctx.d_total
+        seed = _seed(self.global_config)
+        cls = ops.philox_uniform(U.shape[1], seed, 4000 + 2 * self._round, ctx.col_offset, device=U.device)
+        mag = ops.philox_uniform(U.shape[1], seed, 4001 + 2 * self._round, ctx.col_offset, device=U.device)
+        out = torch.where(cls < p_pos, mag, torch.where(cls < p_pos + p_neg, -mag, torch.zeros_like(mag)))
+        out = torch.where(valid, out, torch.zeros_like(out))
+        ops.set_rows_(U, algorithm.malicious_rows, out)
+        return out
+
+
+class AttackclippedclusteringAdversary(Adversary):
+    """Chain attack against ClippedClustering
+    (``attackclippedclustering_adversary.py:24-97``): malicious client t gets the
+    benign direction rotated a further ``theta_cross`` away from the benign mean,
+    scaled by 10, so that single-linkage clustering chains the attackers onto the
+    benign cluster.
+
+    Every crafted vector is ``alpha_t * mean + beta_t * x_far`` for scalars that
+    follow from norms and dot products (Gram GEMM + two row reductions), so only
+    the final row writes touch D-sized data.  Two reference quirks are kept:
+    ``dis_cross`` is the minimum over **all** pairs (the loop never checks the
+    labels, ``:47-53``), and the arg-max index found inside the larger cluster
+    is applied to the full benign set (``:73-76``).
+    """
+
+    def __init__(self, clients, global_config: Dict = None, linkage="single"):
+        super().__init__(clients, global_config)
+        self.linkage = linkage
+
+    def forge(self, algorithm, U, ctx):
+        bm = algorithm.benign_mask > 0
+        bidx = torch.nonzero(bm).flatten()
+        mean = ops.col_mean(U, algorithm.benign_mask)
+        G = global_gram(U, ctx)[bm][:, bm]
+        dots = ops.row_dot(U, mean)
+        mm = (mean * mean).sum().unsqueeze(0)
+        if ctx.distributed:
+            ctx.all_reduce(dots), ctx.all_reduce(mm)
+        dots = dots[bm].double().cpu().numpy()
+        mean_norm = float(mm.sqrt())
+        norms = G.diagonal().clamp_min(0).sqrt().double().cpu().numpy()
+        dis = cosine_distance_from_gram(G)
+        num = len(norms)
+        labels = host.agglomerative2(dis, "single")
+        off = dis + np.eye(num) * 10.0
+        dis_cross = float(off.min()) if num > 1 else 0.0
+        theta_cross = math.acos(max(-1.0, min(1.0, 1 - dis_cross))) - 0.1
+        flag = 1 if labels.sum() > num // 2 else 0
+        larger = np.nonzero(labels == flag)[0]
+        cos2mean = dots / np.maximum(norms * mean_norm, 1e-16)
+        idx_max = int(np.argmax(1 - cos2mean[larger]))
+        theta = math.acos(max(-1.0, min(1.0, cos2mean[larger][idx_max])))
+        far = idx_max  # (sic) index into the full benign set, see docstring
+        # mal = alpha * mean + beta * x_far
+        alpha, beta = 0.0, 1.0 / max(norms[far], 1e-16)
+        x_far = U[bidx[far]].clone()
+        rows = algorithm.malicious_rows.tolist()
+        for r in rows:
+            if theta + theta_cross >= math.pi:
+                alpha, beta = -10.0, 0.0
+            else:
+                t = math.tan(theta)
+                ca = math.cos(theta + theta_cross - 1e-4) - math.sin(theta + theta_cross - 1e-4) / t
+                cb = math.cos(theta_cross - 1e-4) + math.sin(theta_cross - 1e-4) / t
+                alpha, beta = 10 * (ca / mean_norm + cb * alpha), 10 * cb * beta
+                theta = theta + theta_cross - 1e-4
+            U[r] = alpha * mean + beta * x_far

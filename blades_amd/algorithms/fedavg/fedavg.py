@@ -1,0 +1,248 @@
+"""FedAvg / FedSGD under attack — the FL round loop.
+
+Same contract as ``blades/algorithms/fedavg/fedavg.py`` (config keys,
+``training_step`` / ``evaluate`` results, first ``num_malicious_clients``
+clients are the adversary's), different machine mapping:
+
+====================  ======================================================
+reference (Ray)       here (one process per MI355X)
+====================  ======================================================
+weights -> W actors   nothing to send: ``theta`` is replicated, refreshed by
+(pickled closure)     the all-gather that ends the server step
+K RPCs, one client    ``ClientEngine.train_round``: all clients of the rank
+at a time per actor   batched through shared/per-client-weight kernels
+K result dicts ->     update matrix stays in HBM; one RCCL all-to-all turns
+driver (plasma)       the row shard into the column shard
+adversary on a        adversary forges rows of the resident column shard
+``vstack``            (fused mean/std kernels + tiny all-reduces)
+aggregator on the     aggregator kernels on the column shard; fused server
+CPU, ``opt.step()``   step on the slice; all-gather of ``theta``
+====================  ======================================================
+"""
+import time
+from collections import defaultdict
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from blades_amd.adversaries import AdversaryConfig
+from blades_amd.algorithms import Algorithm, AlgorithmConfig
+from blades_amd.clients import ClientConfig
+from blades_amd.constants import CLIENT_UPDATE, NUM_GLOBAL_STEPS
+from blades_amd.datasets.catalog import DatasetCatalog
+from blades_amd.engine.trainer import ClientEngine
+from blades_amd.parallel.runtime import get_runtime
+from blades_amd.parallel.worker_group_config import WorkerGroupConfig
+from blades_amd.types import NotProvided
+from blades_amd.utils.from_config import deep_update
+from blades_amd.utils.timers import PhaseTimers
+from blades_amd.utils.torch_utils import set_torch_seed
+
+
+class FedavgConfig(AlgorithmConfig):
+    def __init__(self, algo_class=None):
+        super().__init__(algo_class=algo_class or Fedavg)
+        self.adversary_config = {}
+        self.num_malicious_clients = 0
+
+    def adversary(self, *, num_malicious_clients: Optional[int] = NotProvided,
+                  adversary_config: Optional[Dict] = NotProvided):
+        if adversary_config is not NotProvided:
+            deep_update(self.adversary_config, adversary_config, True)
+        if num_malicious_clients is not NotProvided:
+            self.num_malicious_clients = num_malicious_clients
+        return self
+
+    def get_adversary_config(self) -> AdversaryConfig:
+        self._require_frozen("get_adversary_config")
+        return AdversaryConfig(adversary_cls=self.adversary_config.get("type", "blades_amd.adversaries.Adversary"),
+                               config=self).update_from_dict(self.adversary_config)
+
+    def get_client_config(self) -> ClientConfig:
+        return ClientConfig(class_specifier="blades_amd.clients.Client").update_from_dict(self.client_config)
+
+    def validate(self) -> None:
+        super().validate()
+        # DnC / Trimmedmean / Multikrum learn the number of attackers from the
+        # experiment (reference fedavg.py:94-107).
+        agg = self.server_config.get("aggregator", None) if isinstance(self.server_config, dict) else None
+        if isinstance(agg, dict) and agg.get("type") is not None:
+            t = str(agg["type"])
+            if t.rpartition(".")[2] == "DnC" or "Trimmedmean" in t or "Multikrum" in t:
+                agg["num_byzantine"] = self.num_malicious_clients
+        if self.num_malicious_clients > self.num_clients:
+            raise ValueError("`num_malicious_clients` must be smaller than or equal `num_clients`! "
+                             "Simulation makes no sense otherwise.")
+
+
+class _ResultRow(dict):
+    """Reference-style per-client result dict backed by a row of the update matrix."""
+
+
+class Fedavg(Algorithm):
+    def __init__(self, config=None, logger_creator=None, **kwargs):
+        self.local_results: List[dict] = []
+        super().__init__(config, logger_creator, **kwargs)
+
+    @classmethod
+    def get_default_config(cls) -> AlgorithmConfig:
+        return FedavgConfig()
+
+    # ------------------------------------------------------------------
+    def setup(self, config: AlgorithmConfig):
+        self.config = config
+        set_torch_seed(config.seed)
+        self.rt = get_runtime()
+        want_gpu = (config.num_gpus_for_driver or 0) > 0 or (config.num_gpus_per_worker or 0) > 0
+        if config.device != "auto":
+            self.device = torch.device(config.device)
+        else:
+            self.device = self.rt.device if (want_gpu or self.rt.device.type == "cuda") else torch.device("cpu")
+        self._timers = PhaseTimers(self.device)
+        self._counters = defaultdict(int)
+
+        from blades_amd.parallel.context import ShardContext
+
+        ctx = ShardContext(d_total=0, world_size=self.rt.world_size, rank=self.rt.rank)
+        self.server = config.get_server_config().build(self.device, ctx=ctx)
+        self.ctx = self.server.ctx
+
+        self.worker_group = self._setup_worker_group()
+        self._setup_dataset()
+        self.client_manager = self.client_manager_cls(self._dataset.client_ids,
+                                                      client_config=config.get_client_config())
+        clients = self.client_manager.clients
+        self.worker_group.local_execute(lambda _, client: client.setup(), clients)
+
+        self.adversary = config.get_adversary_config().build(clients[: config.num_malicious_clients])
+        self.adversary.on_algorithm_start(self)
+
+        ccfg = config.get_client_config()
+        dc = config.dataset_config
+        self.engine = ClientEngine(
+            task=self.server.task, dataset=self._dataset, clients=clients, runtime=self._engine_runtime(),
+            client_lr=ccfg.lr, client_momentum=ccfg.momentum, num_batch_per_round=ccfg.num_batch_per_round,
+            batch_size=self._dataset.train_bs, seed=config.seed, clients_per_chunk=config.clients_per_chunk,
+            amp_dtype=config.amp_dtype, execution_mode=config.execution_mode,
+            num_classes=dc.get("num_classes"))
+        self._malicious_flags = [bool(c.is_malicious) for c in clients]
+        self._benign_mask = self.engine.row_mask([not m for m in self._malicious_flags])
+        self._malicious_rows = torch.nonzero(self._benign_mask == 0).flatten()
+        self.update_matrix: Optional[torch.Tensor] = None
+
+    def _engine_runtime(self):
+        from blades_amd.parallel.runtime import Runtime
+
+        return Runtime(self.rt.rank, self.rt.world_size, self.rt.local_rank, self.device, self.rt.backend)
+
+    def _setup_worker_group(self):
+        wg = self.config.get_worker_group_config().build(device=str(self.device))
+        wg.local_worker().bind_task(self.server.task)  # sequential path shares the server's model
+        return wg
+
+    def _setup_dataset(self):
+        self._dataset = DatasetCatalog.get_dataset(self.config.dataset_config)
+        self.worker_group.local_worker().dataset = self._dataset
+
+    @property
+    def dataset(self):
+        return self._dataset
+
+    # -- row-order helpers for adversaries ------------------------------------
+    @property
+    def benign_mask(self) -> torch.Tensor:
+        """[K] float mask (global row order): 1 for non-malicious clients."""
+        return self._benign_mask
+
+    @property
+    def malicious_rows(self) -> torch.Tensor:
+        return self._malicious_rows
+
+    def _build_local_results(self, U: torch.Tensor):
+        """Reference-style ``local_results`` view (single rank only): a list of
+        ``{"id", CLIENT_UPDATE}`` dicts whose tensors alias rows of ``U``."""
+        res = []
+        for i, c in enumerate(self.client_manager.clients):
+            row = int(self.engine.plan.row_of_client[i])
+            d = _ResultRow(id=c.client_id)
+            if getattr(c, "local_training", True):
+                d[CLIENT_UPDATE] = U[row, : self.engine.D]
+            res.append(d)
+        return res
+
+    def _writeback_local_results(self, U: torch.Tensor):
+        for i, d in enumerate(self.local_results):
+            row = int(self.engine.plan.row_of_client[i])
+            v = d.get(CLIENT_UPDATE, None)
+            if v is None:
+                continue
+            tgt = U[row, : self.engine.D]
+            if v.data_ptr() != tgt.data_ptr():
+                tgt.copy_(v.to(tgt.device))
+
+    # ------------------------------------------------------------------
+    def training_step(self):
+        T = self._timers
+        with T("local_train"):
+            U, loss_sum, loss_cnt = self.engine.train_round(self.server.theta)
+        self.update_matrix = U
+        with T("attack"):
+            if self.adversary.uses_local_results:
+                if self.ctx.distributed:
+                    raise RuntimeError(f"{type(self.adversary).__name__} only implements the reference-style "
+                                       "`local_results` interface, which needs world_size == 1.")
+                self.local_results = self._build_local_results(U)
+                self.adversary.on_local_round_end(self)
+                self._writeback_local_results(U)
+            else:
+                self.adversary.on_local_round_end(self)
+        self._counters[NUM_GLOBAL_STEPS] += 1
+        global_vars = {"timestep": self._counters[NUM_GLOBAL_STEPS]}
+        with T("aggregate_and_step"):
+            server_return = self.server.step(U, global_vars)
+        stats = torch.stack([loss_sum, loss_cnt]).tolist()  # the round's single host sync
+        results = {"train_loss": stats[0] / stats[1] if stats[1] > 0 else float("nan")}
+        results.update(server_return)
+        results["timers"] = T.snapshot()
+        results["timers"].update({k: v for k, v in self.engine.timers.items()})
+        info = getattr(self.server.aggregator, "last_info", None)
+        if info and "num_selected" in info:
+            results["num_selected_clients"] = int(info["num_selected"])
+        return results
+
+    def evaluate(self):
+        with self._timers("evaluate"):
+            r = self.engine.evaluate(self.server.theta)
+        return {"ce_loss": r["ce_loss"], "acc_top_1": r["acc_top_1"]}
+
+    # -- checkpoint -----------------------------------------------------
+    def __getstate__(self) -> Dict:
+        state = super().__getstate__()
+        state.update({
+            "server": self.server.state_dict(),
+            "engine": self.engine.state_dict(),
+            "adversary": self.adversary.state_dict(),
+            "counters": dict(self._counters),
+            "torch_rng": torch.get_rng_state(),
+            "numpy_rng": np.random.get_state(),
+            "world_size": self.rt.world_size,
+        })
+        return state
+
+    def __setstate__(self, state: Dict):
+        super().__setstate__(state)
+        if "server" in state:
+            self.server.load_state_dict(state["server"])
+            if state.get("world_size", 1) == self.rt.world_size:
+                self.engine.load_state_dict(state["engine"])
+            self.adversary.load_state_dict(state.get("adversary", {}))
+            self._counters.update(state.get("counters", {}))
+            torch.set_rng_state(state["torch_rng"])
+            np.random.set_state(state["numpy_rng"])
+
+    def save_checkpoint(self, checkpoint_dir: str) -> str:
+        if self.rt.is_main:
+            return super().save_checkpoint(checkpoint_dir)
+        self.__getstate__()  # collectives inside state_dict must run on every rank
+        return checkpoint_dir

@@ -1,0 +1,63 @@
+"""ServerConfig (reference ``fllib/algorithms/server_config.py``).
+
+Note on a reference quirk: there ``build(use_copy=True, device="cpu")`` is
+called as ``build(server_device)`` (``blades/.../fedavg.py:143``), so the device
+lands in ``use_copy`` and the server always lives on the CPU.  Here the first
+positional argument *is* the device and the server lives where the rank's
+update matrix lives (the GPU).
+"""
+import copy
+import logging
+from typing import Callable, Dict, Optional
+
+from blades_amd.types import NotProvided
+from blades_amd.utils.from_config import from_config, log_once
+
+logger = logging.getLogger(__name__)
+
+
+class ServerConfig:
+    def __init__(self, class_specifier, task_spec) -> None:
+        self.cls = class_specifier
+        self.task_spec = task_spec
+        self.aggregator = "Mean"
+        self.optimizer = {}
+
+    def training(self, task_spec=NotProvided, aggregator: Optional[Dict] = NotProvided,
+                 optimizer: Optional[Dict] = NotProvided) -> "ServerConfig":
+        if task_spec is not NotProvided:
+            self.task_spec = task_spec
+        if aggregator is not NotProvided:
+            self.aggregator = aggregator
+        if optimizer is not NotProvided:
+            self.optimizer = optimizer
+        return self
+
+    def __getitem__(self, item):
+        return getattr(self, item)
+
+    def build(self, device="cpu", use_copy: bool = True, ctx=None) -> Callable:
+        if self.cls is None:
+            raise ValueError("server_cls is not set")
+        if isinstance(device, bool):  # tolerate the reference's argument order
+            device, use_copy = "cpu", device
+        return from_config(self.cls, None, task_spec=self.task_spec, device=str(device),
+                           optimizer_config=copy.deepcopy(self.optimizer),
+                           aggregator_config=copy.deepcopy(self.aggregator), ctx=ctx)
+
+    def to_dict(self) -> dict:
+        d = dict(vars(self))
+        d["task_spec"] = getattr(self.task_spec, "task_class", None)
+        return copy.deepcopy(d)
+
+    def update_from_dict(self, config_dict) -> "ServerConfig":
+        for key, value in config_dict.items():
+            if key == "lr":
+                self.optimizer.update(lr=value)
+            if key in ("aggregator", "optimizer"):
+                self.training(**{key: value})
+            else:
+                if not hasattr(self, key) and log_once("unknown_property_in_server_config_" + key):
+                    logger.warning(f"{type(self).__name__}: unknown property `{key}` set from dict.")
+                setattr(self, key, value)
+        return self

@@ -106,6 +106,12 @@ def sqdist_to(U, m):
     return ref.sqdist_to(U, m)
 
 
+def row_dot(U, v):
+    if _use_hip(_f32c(U)):
+        return _hip().row_dot(U, v)
+    return ref.row_dot(U, v)
+
+
 def gram(U):
     if _use_hip(_f32c(U)):
         return _hip().gram(U)

@@ -91,6 +91,11 @@ def sqdist_to(U: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
     return (d * d).sum(dim=1)
 
 
+def row_dot(U: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """``out[i] = sum_j U[i,j] * v[j]`` (partial over the local columns)."""
+    return torch.mv(U, v.to(U.dtype))
+
+
 def gram(U: torch.Tensor) -> torch.Tensor:
     """``U @ U.T`` in fp32 (partial over the local columns)."""
     return U @ U.t()
