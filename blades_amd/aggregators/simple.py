@@ -118,7 +118,7 @@ class DnC(Aggregator):
     """
 
     def __init__(self, num_byzantine, *, sub_dim=10000, num_iters=5, filter_frac=1.0,
-                 power_iters: int = 200, seed: int = 0):
+                 power_iters: int = 8, seed: int = 0):
         super().__init__()
         self.num_byzantine = num_byzantine
         self.sub_dim = sub_dim

@@ -172,7 +172,6 @@ def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, over
     return ref.add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite)
 
 
-def power_iteration_top(G, iters=100):
-    if G.is_cuda and not _FORCE_REFERENCE:
-        return _hip().power_iteration_top(G, iters)
+def power_iteration_top(G, iters=8):
+    # K x K linear algebra (K = clients): library GEMMs on either device.
     return ref.power_iteration_top(G, iters)

@@ -1,0 +1,272 @@
+"""ctypes bindings of ``libblades_hip.so`` — the hand-written gfx950 kernels.
+
+Kernels are launched on PyTorch's *current* HIP stream with raw device
+pointers, so they order correctly with surrounding torch ops and are captured
+by ``torch.cuda.graphs``.  Shapes/strides/dtypes are validated here on the host
+before every launch: an out-of-bounds access in a kernel can take the whole
+node down, so nothing reaches a kernel unchecked.
+
+Importing this module without the built library raises — GPU tensors never
+fall back to a PyTorch implementation.
+"""
+import ctypes
+from ctypes import c_float, c_int, c_long, c_longlong, c_uint, c_ulonglong, c_void_p
+from typing import Optional
+
+import torch
+
+from . import build as _build
+
+if not _build.HIP_LIB.exists():
+    raise ImportError(
+        f"{_build.HIP_LIB} is missing: build it with `python -m blades_amd.ops.build` "
+        "(hipcc cross-compiles gfx950 without a GPU). GPU tensors have no other implementation."
+    )
+
+_lib = ctypes.CDLL(str(_build.HIP_LIB))
+
+_P = c_void_p
+
+
+def _sig(name, argtypes, restype=None):
+    fn = getattr(_lib, name)
+    fn.argtypes = argtypes
+    fn.restype = restype
+    return fn
+
+
+_weighted_col_sum = _sig("blades_weighted_col_sum", [_P, c_long, c_int, c_long, _P, _P, _P])
+_col_stats = _sig("blades_col_stats", [_P, c_long, c_int, c_long, _P, _P, _P, _P, _P, c_int, c_float, c_float, _P, _P,
+                                       c_int, _P, _P])
+_set_rows = _sig("blades_set_rows", [_P, c_long, c_long, _P, c_int, _P, _P])
+_row_scale = _sig("blades_row_scale", [_P, c_long, c_int, c_long, _P, _P])
+_col_order_stat = _sig("blades_col_order_stat", [_P, c_long, c_int, c_long, _P, c_int, c_int, _P, _P], c_int)
+_row_chunks = _sig("blades_row_chunks", [c_long], c_int)
+_row_reduce = _sig("blades_row_reduce", [_P, c_long, c_int, c_long, c_long, _P, c_int, _P, _P, _P, _P, _P])
+_server_step = _sig("blades_server_step", [_P, _P, _P, c_long, c_float, c_float, c_int, _P])
+_client_sgd = _sig("blades_client_sgd_step", [_P, _P, _P, c_int, c_long, c_long, c_long, c_long, c_float, c_float,
+                                              c_int, _P, _P])
+_philox_uniform = _sig("blades_philox_uniform", [_P, c_long, c_ulonglong, c_uint, c_ulonglong, _P])
+_philox_normal = _sig("blades_philox_normal", [_P, c_long, c_ulonglong, c_uint, c_ulonglong, c_float, c_float, _P])
+_normal_rows = _sig("blades_normal_rows", [_P, c_long, c_long, _P, c_int, c_long, c_long, c_ulonglong, c_uint,
+                                           c_float, c_float, c_int, _P])
+_gram_plan = _sig("blades_gram_plan", [c_int, c_long, _P, _P, _P, _P])
+_gram = _sig("blades_gram", [_P, c_long, c_int, c_long, _P, _P, _P])
+_augment = _sig("blades_augment_batch", [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P], c_int)
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_matrix(U: torch.Tensor):
+    if not (U.is_cuda and U.dtype == torch.float32 and U.dim() == 2 and U.stride(1) == 1):
+        raise ValueError(f"expected a CUDA fp32 [K, D] matrix with unit column stride, got {U.dtype} {tuple(U.shape)} "
+                         f"strides {U.stride()}")
+    K, Dl = U.shape
+    ld = U.stride(0) if K > 1 else max(U.stride(0), Dl)
+    if ld < Dl:
+        raise ValueError("row stride smaller than the row length")
+    return K, Dl, ld
+
+
+def _vec(t: Optional[torch.Tensor], n: int, device, dtype=torch.float32, name="vector") -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    t = t.to(device=device, dtype=dtype).contiguous()
+    if t.numel() != n:
+        raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else c_void_p(0)
+
+
+def _rows(rows: torch.Tensor, K: int, device) -> torch.Tensor:
+    rows = rows.to(device="cpu", dtype=torch.int64).flatten()
+    if rows.numel() and (int(rows.min()) < 0 or int(rows.max()) >= K):
+        raise IndexError("row index out of range")
+    return rows.to(device).contiguous()
+
+
+# ---------------------------------------------------------------------------
+def weighted_col_sum(U, w):
+    K, Dl, ld = _chk_matrix(U)
+    w = _vec(w, K, U.device, name="w")
+    out = torch.empty(Dl, device=U.device, dtype=torch.float32)
+    _weighted_col_sum(_ptr(U), ld, K, Dl, _ptr(w), _ptr(out), _stream())
+    return out
+
+
+def _col_stats_call(U, mask, mode, a=1.0, z=0.0, sign=None, mal_rows=None):
+    K, Dl, ld = _chk_matrix(U)
+    dev = U.device
+    mask = _vec(mask, K, dev, name="mask")
+    want_std, want_mm, forge = bool(mode & 1), bool(mode & 2), bool(mode & 4)
+    mean = torch.empty(Dl, device=dev)
+    std = torch.empty(Dl, device=dev) if want_std else None
+    mn = torch.empty(Dl, device=dev) if want_mm else None
+    mx = torch.empty(Dl, device=dev) if want_mm else None
+    vec = torch.empty(Dl, device=dev) if forge else None
+    sign = _vec(sign, Dl, dev, name="sign")
+    n_mal = 0
+    if forge and mal_rows is not None and mal_rows.numel():
+        mal_rows = _rows(mal_rows, K, dev)
+        n_mal = mal_rows.numel()
+    else:
+        mal_rows = None
+    _col_stats(_ptr(U), ld, K, Dl, _ptr(mask), _ptr(mean), _ptr(std), _ptr(mn), _ptr(mx), mode, a, z, _ptr(sign),
+               _ptr(mal_rows), n_mal, _ptr(vec), _stream())
+    return mean, std, mn, mx, vec
+
+
+def col_mean_std(U, mask=None):
+    mean, std, _, _, _ = _col_stats_call(U, mask, 1)
+    return mean, std
+
+
+def col_min_max(U, mask=None):
+    _, _, mn, mx, _ = _col_stats_call(U, mask, 2)
+    return mn, mx
+
+
+def alie_forge_(U, benign_mask, mal_rows, z, sign=None):
+    return _col_stats_call(U, benign_mask, 5, 1.0, z, sign, mal_rows)[4]
+
+
+def ipm_forge_(U, benign_mask, mal_rows, scale):
+    return _col_stats_call(U, benign_mask, 4, -scale, 0.0, None, mal_rows)[4]
+
+
+def set_rows_(U, rows, v):
+    K, Dl, ld = _chk_matrix(U)
+    rows = _rows(rows, K, U.device)
+    v = _vec(v, Dl, U.device, name="v")
+    _set_rows(_ptr(U), ld, Dl, _ptr(rows), rows.numel(), _ptr(v), _stream())
+    return U
+
+
+def row_scale_(U, s):
+    K, Dl, ld = _chk_matrix(U)
+    s = _vec(s, K, U.device, name="s")
+    _row_scale(_ptr(U), ld, K, Dl, _ptr(s), _stream())
+    return U
+
+
+def col_order_stat(U, mask, mode: int, b: int):
+    K, Dl, ld = _chk_matrix(U)
+    mask = _vec(mask, K, U.device, name="mask")
+    out = torch.empty(Dl, device=U.device)
+    rc = _col_order_stat(_ptr(U), ld, K, Dl, _ptr(mask), mode, b, _ptr(out), _stream())
+    if rc != 0:
+        raise ValueError(f"col_order_stat supports up to 2048 rows, got {K}")
+    return out
+
+
+def _row_reduce_call(U, kind, m=None, valid_cols=None, counts=False):
+    K, Dl, ld = _chk_matrix(U)
+    dev = U.device
+    m = _vec(m, Dl, dev, name="m")
+    nch = _row_chunks(Dl)
+    part = torch.empty(K * nch, device=dev)
+    cpart = torch.empty(K * nch * 3, device=dev, dtype=torch.int32) if counts else None
+    out = torch.empty(K, device=dev)
+    cnt = torch.empty(K, 3, device=dev, dtype=torch.int64) if counts else None
+    _row_reduce(_ptr(U), ld, K, Dl, Dl if valid_cols is None else int(valid_cols), _ptr(m), kind, _ptr(part),
+                _ptr(cpart), _ptr(out), _ptr(cnt), _stream())
+    return out, cnt
+
+
+def row_stats(U, valid_cols, counts=True):
+    return _row_reduce_call(U, 0, None, valid_cols, counts)
+
+
+def sqdist_to(U, m):
+    return _row_reduce_call(U, 1, m)[0]
+
+
+def row_dot(U, v):
+    return _row_reduce_call(U, 2, v)[0]
+
+
+def gram(U):
+    K, Dl, ld = _chk_matrix(U)
+    tile, ntile, nsplit, cps = c_int(), c_int(), c_int(), c_long()
+    _gram_plan(K, Dl, ctypes.byref(tile), ctypes.byref(ntile), ctypes.byref(nsplit), ctypes.byref(cps))
+    Kp = tile.value * ntile.value
+    slabs = torch.empty(max(nsplit.value, 1) * Kp * Kp, device=U.device)
+    out = torch.empty(K, K, device=U.device)
+    _gram(_ptr(U), ld, K, Dl, _ptr(slabs), _ptr(out), _stream())
+    return out
+
+
+def server_step_(theta, buf, agg, lr, momentum, first):
+    n = theta.numel()
+    for t in (theta, agg) + ((buf,) if momentum != 0.0 else ()):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+            raise ValueError("server_step_: need contiguous fp32 CUDA vectors of equal length")
+    _server_step(_ptr(theta), _ptr(buf if momentum != 0.0 else theta), _ptr(agg), n, lr, momentum, int(first),
+                 _stream())
+    return theta
+
+
+def client_sgd_step_(W, G, M, lr, momentum, first, gscale=None):
+    Kc, D, ldw = _chk_matrix(W)
+    Kg, Dg, ldg = _chk_matrix(G)
+    if (Kg, Dg) != (Kc, D):
+        raise ValueError("client_sgd_step_: W and G shapes differ")
+    ldm = 0
+    if momentum != 0.0:
+        Km, Dm, ldm = _chk_matrix(M)
+        if (Km, Dm) != (Kc, D):
+            raise ValueError("client_sgd_step_: momentum buffer shape differs")
+    gscale = _vec(gscale, Kc, W.device, name="gscale")
+    _client_sgd(_ptr(W), _ptr(G), _ptr(M) if momentum != 0.0 else c_void_p(0), Kc, D, ldw, ldg, ldm, lr, momentum,
+                int(first), _ptr(gscale), _stream())
+    return W
+
+
+def philox_uniform(n, seed, stream, offset, device):
+    out = torch.empty(n, device=device, dtype=torch.float32)
+    _philox_uniform(_ptr(out), n, seed & (2 ** 64 - 1), stream & 0xFFFFFFFF, offset, _stream())
+    return out
+
+
+def philox_normal(n, seed, stream, offset, mean, std, device):
+    out = torch.empty(n, device=device, dtype=torch.float32)
+    _philox_normal(_ptr(out), n, seed & (2 ** 64 - 1), stream & 0xFFFFFFFF, offset, mean, std, _stream())
+    return out
+
+
+def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite):
+    K, Dl, ld = _chk_matrix(U)
+    rows = rows.to(dtype=torch.int64, device="cpu").reshape(-1, 2)
+    if rows.numel() and (int(rows[:, 0].min()) < 0 or int(rows[:, 0].max()) >= K):
+        raise IndexError("row index out of range")
+    rd = rows.to(U.device).contiguous()
+    _normal_rows(_ptr(U), ld, Dl, _ptr(rd), rows.shape[0], col_offset, d_total, seed & (2 ** 64 - 1),
+                 stream & 0xFFFFFFFF, mean, std, int(overwrite), _stream())
+    return U
+
+
+def augment_batch(x, params, size, mean, std):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5):
+        raise ValueError("augment_batch: x must be CUDA fp32 [n, B, C, H, W]")
+    x = x.contiguous()
+    n, B, C, H, W = x.shape
+    params = params.to(device=x.device, dtype=torch.float32).contiguous()
+    if params.shape != (n, 9):
+        raise ValueError("augment_batch: params must be [n, 9]")
+    pc = params.cpu()
+    # crop window must lie inside the image (checked on the host: see module docstring)
+    if n and (float((pc[:, 0] + pc[:, 2]).max()) > H or float((pc[:, 1] + pc[:, 2]).max()) > W
+              or float(pc[:, :3].min()) < 0 or float(pc[:, 2].min()) < 1):
+        raise ValueError("augment_batch: crop window out of bounds")
+    out = torch.empty(n, B, C, size, size, device=x.device, dtype=torch.float32)
+    m = (c_float * 4)(*(list(mean) + [0.0] * 4)[:4])
+    s = (c_float * 4)(*(list(std) + [1.0] * 4)[:4])
+    rc = _augment(_ptr(x), _ptr(params), _ptr(out), n, B, C, H, W, size, m, s, _stream())
+    if rc != 0:
+        raise ValueError("augment_batch supports up to 4 channels")
+    return out

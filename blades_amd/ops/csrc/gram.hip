@@ -1,0 +1,165 @@
+// Gram matrix G = U U^T of the update matrix U[K, Dl] with exact-fp32 MFMA.
+//
+// This is the GEMM behind every pairwise-distance / cosine statistic
+// (Multi-Krum, ClippedClustering, MinMax, DnC).  fp32 inputs go
+// straight to v_mfma_f32_32x32x2_f32 — bit-for-bit an fp32 fmaf chain, no
+// reduced-precision detour, because the consumers subtract nearly equal numbers
+// (g_ii + g_jj - 2 g_ij).
+//
+// Shape is "K tiny, reduction huge" (K <= ~2048 rows, Dl up to 11 M columns), so
+// parallelism comes from split-K: block (pair, split) computes one BxB tile of the
+// upper triangle over a column range and writes an fp32 slab; a second kernel adds
+// the slabs in fixed order (deterministic) and mirrors the lower triangle.
+//
+// Tile: 256 threads = 2x2 waves, each wave (B/2)x(B/2) out of 32x32 MFMA blocks,
+// BK = 32 columns per step staged global -> registers -> LDS with a 36-float row
+// stride (conflict-free ds_read_b128, see cdna guide §2).  The k index inside a
+// step is permuted identically for both operands (lane half h reads the 4
+// consecutive floats 8t+4h..8t+4h+3 with one b128 and feeds them to 4 MFMAs), which
+// a dot product does not care about.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;
+
+template <int B>
+__global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict__ U, long ld, int K, long Dl,
+                                                        long cols_per_split, int ntile, int Kp,
+                                                        float* __restrict__ slabs) {
+  constexpr int T = B / 64;  // MFMA blocks per wave per dim
+  __shared__ __attribute__((aligned(16))) float lds[2 * B * LDS_LD];
+  float* As = lds;
+  float* Bs = lds + B * LDS_LD;
+  // decode upper-triangular tile pair
+  int pair = blockIdx.x, ti = 0;
+  while (pair >= ntile - ti) { pair -= ntile - ti; ++ti; }
+  const int tj = ti + pair;
+  const long c_begin = (long)blockIdx.y * cols_per_split;
+  long c_end = c_begin + cols_per_split;
+  if (c_end > Dl) c_end = Dl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+  const bool al = (ld & 3) == 0;
+
+  f32x16 acc[T][T];
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+  constexpr int F4_PER_TILE = B * (BK / 4);      // float4 per operand tile
+  constexpr int LOADS = F4_PER_TILE / 256;        // per thread per operand
+  for (long c0 = c_begin; c0 < c_end; c0 += BK) {
+    f32x4 ra[LOADS], rb[LOADS];
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int f = q * 256 + tid;
+      const int row = f / (BK / 4), k4 = (f % (BK / 4)) * 4;
+      const long col = c0 + k4;
+      const int ga = ti * B + row, gb = tj * B + row;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      if (col + 4 <= c_end && al) {
+        if (ga < K) va = *reinterpret_cast<const f32x4*>(U + (long)ga * ld + col);
+        if (gb < K) vb = *reinterpret_cast<const f32x4*>(U + (long)gb * ld + col);
+      } else {
+        for (int j = 0; j < 4; ++j) {
+          if (col + j < c_end) {
+            if (ga < K) va[j] = U[(long)ga * ld + col + j];
+            if (gb < K) vb[j] = U[(long)gb * ld + col + j];
+          }
+        }
+      }
+      ra[q] = va; rb[q] = vb;
+    }
+    __syncthreads();  // previous step's reads done
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int f = q * 256 + tid;
+      const int row = f / (BK / 4), k4 = (f % (BK / 4)) * 4;
+      *reinterpret_cast<f32x4*>(As + row * LDS_LD + k4) = ra[q];
+      *reinterpret_cast<f32x4*>(Bs + row * LDS_LD + k4) = rb[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < BK / 8; ++t) {
+      f32x4 fa[T], fb[T];
+#pragma unroll
+      for (int a = 0; a < T; ++a)
+        fa[a] = *reinterpret_cast<const f32x4*>(As + (wr * (B / 2) + a * 32 + r32) * LDS_LD + t * 8 + h * 4);
+#pragma unroll
+      for (int b = 0; b < T; ++b)
+        fb[b] = *reinterpret_cast<const f32x4*>(Bs + (wc * (B / 2) + b * 32 + r32) * LDS_LD + t * 8 + h * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+          for (int b = 0; b < T; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+    }
+  }
+  // C/D map of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* slab = slabs + (long)blockIdx.y * Kp * Kp;
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = ti * B + wr * (B / 2) + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        const int col = tj * B + wc * (B / 2) + b * 32 + r32;
+        slab[(long)row * Kp + col] = acc[a][b][q];
+      }
+}
+
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nsplit, int Kp, int K,
+                                                          int B, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)K * K) return;
+  const int i = (int)(idx / K), j = (int)(idx % K);
+  // only tiles with tile_row <= tile_col were computed
+  int si = i, sj = j;
+  if (i / B > j / B) { si = j; sj = i; }
+  float acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) acc += slabs[(long)s * Kp * Kp + (long)si * Kp + sj];
+  out[idx] = acc;
+}
+
+}  // namespace
+
+BLADES_API void blades_gram_plan(int K, long Dl, int* tile, int* ntile, int* nsplit, long* cols_per_split) {
+  const int B = K <= 64 ? 64 : 128;
+  const int nt = cdiv(K, B);
+  const int pairs = nt * (nt + 1) / 2;
+  long want = 1024 / pairs;
+  if (want < 1) want = 1;
+  long steps = cdiv(Dl, BK);
+  long min_steps_per_split = 16;  // >= 512 columns per block
+  long max_split = steps / min_steps_per_split;
+  if (max_split < 1) max_split = 1;
+  if (want > max_split) want = max_split;
+  long sps = cdiv(steps, want);
+  *tile = B; *ntile = nt; *cols_per_split = sps * BK; *nsplit = cdiv(Dl, sps * BK);
+}
+
+// slabs: workspace of nsplit * Kp * Kp floats, Kp = ntile * tile
+BLADES_API void blades_gram(const float* U, long ld, int K, long Dl, float* slabs, float* out, hipStream_t st) {
+  if (K <= 0) return;
+  int B, nt, nsplit; long cps;
+  blades_gram_plan(K, Dl, &B, &nt, &nsplit, &cps);
+  const int Kp = nt * B, pairs = nt * (nt + 1) / 2;
+  if (Dl <= 0) { hipMemsetAsync(out, 0, sizeof(float) * K * K, st); return; }
+  if (B == 64)
+    hipLaunchKernelGGL((gram_tile_kernel<64>), dim3(pairs, nsplit), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, slabs);
+  else
+    hipLaunchKernelGGL((gram_tile_kernel<128>), dim3(pairs, nsplit), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, slabs);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)K * K, 256)), dim3(256), 0, st, slabs, nsplit, Kp, K, B, out);
+}

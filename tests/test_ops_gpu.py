@@ -1,0 +1,198 @@
+"""Every HIP kernel against the plain-PyTorch fp32 oracle of the same op."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from blades_amd import ops
+from blades_amd.ops import reference as ref
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from blades_amd.ops import _hip  # noqa: F401  (must load: no fallback on GPU)
+
+    return torch.device("cuda")
+
+
+def make(K, D, dev, seed=0, ld=None):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    U = torch.randn(K, D, generator=g)
+    U[:, ::7] = 0.0  # some exact zeros for the sign counts
+    if ld is not None:
+        buf = torch.zeros(K, ld)
+        buf[:, :D] = U
+        return buf.to(dev)[:, :D]
+    return U.to(dev)
+
+
+SHAPES = [(4, 3), (60, 1000), (61, 4099), (200, 777), (1000, 2048), (33, 100003)]
+
+
+@pytest.mark.parametrize("K,D", SHAPES)
+def test_weighted_col_sum_and_mean(dev, K, D):
+    U = make(K, D, dev)
+    w = torch.rand(K, device=dev)
+    torch.testing.assert_close(ops.weighted_col_sum(U, w), ref.weighted_col_sum(U, w), rtol=1e-4, atol=1e-4)
+    mask = (torch.rand(K, device=dev) > 0.3).float()
+    mask[0] = 1
+    torch.testing.assert_close(ops.col_mean(U, mask), ref.col_mean(U, mask), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("K,D", SHAPES)
+def test_col_mean_std_minmax(dev, K, D):
+    U = make(K, D, dev, ld=D + 8 if D % 4 == 0 else None)
+    mask = (torch.rand(K, device=dev) > 0.3).float()
+    mask[:2] = 1
+    for m in (None, mask):
+        mean, std = ops.col_mean_std(U, m)
+        rmean, rstd = ref.col_mean_std(U, m)
+        torch.testing.assert_close(mean, rmean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(std, rstd, rtol=1e-4, atol=1e-5)
+        mn, mx = ops.col_min_max(U, m)
+        rmn, rmx = ref.col_min_max(U, m)
+        assert torch.equal(mn, rmn) and torch.equal(mx, rmx)
+
+
+@pytest.mark.parametrize("K,D", SHAPES + [(64, 100), (65, 100), (128, 50), (129, 70), (512, 40), (513, 40), (1025, 24),
+                                          (2048, 16)])
+def test_median_trimmed(dev, K, D):
+    U = make(K, D, dev)
+    torch.testing.assert_close(ops.col_median(U), ref.col_median(U), rtol=0, atol=1e-6)
+    b = max(0, min(K // 2 - 1, K // 5))
+    torch.testing.assert_close(ops.col_trimmed_mean(U, b), ref.col_trimmed_mean(U, b), rtol=1e-4, atol=1e-5)
+    mask = (torch.rand(K, device=dev) > 0.4).float()
+    mask[:3] = 1
+    torch.testing.assert_close(ops.col_median(U, mask), ref.col_median(U, mask), rtol=0, atol=1e-6)
+    nb = int(mask.sum())
+    bb = max(0, min(nb // 2 - 1, 2))
+    torch.testing.assert_close(ops.col_trimmed_mean(U, bb, mask), ref.col_trimmed_mean(U, bb, mask), rtol=1e-4,
+                               atol=1e-5)
+
+
+def test_median_oracle_4x3(dev):
+    U = torch.tensor([[1, 2, 3], [-1, 4, -1], [2.0, 2, 3], [3.0, 1.0, 3]], device=dev)
+    torch.testing.assert_close(ops.col_median(U), torch.tensor([1.5, 2.0, 3.0], device=dev))
+    torch.testing.assert_close(ops.col_trimmed_mean(U, 1), torch.tensor([1.5, 2.0, 3.0], device=dev))
+    torch.testing.assert_close(ops.col_mean(U), torch.tensor([1.25, 2.25, 2.0], device=dev))
+
+
+@pytest.mark.parametrize("K,D", SHAPES)
+def test_row_reductions(dev, K, D):
+    U = make(K, D, dev)
+    sq, cnt = ops.row_stats(U)
+    rsq, rcnt = ref.row_stats(U)
+    torch.testing.assert_close(sq, rsq, rtol=1e-4, atol=1e-4)
+    assert torch.equal(cnt, rcnt)
+    valid = max(1, D - 3)
+    sq2, cnt2 = ops.row_stats(U, valid)
+    rsq2, rcnt2 = ref.row_stats(U, valid)
+    torch.testing.assert_close(sq2, rsq2, rtol=1e-4, atol=1e-4)
+    assert torch.equal(cnt2, rcnt2)
+    m = torch.randn(D, device=dev)
+    torch.testing.assert_close(ops.sqdist_to(U, m), ref.sqdist_to(U, m), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(ops.row_dot(U, m), ref.row_dot(U, m), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(ops.row_sqnorm(U), rsq, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("K,D", SHAPES + [(130, 5000), (257, 300)])
+def test_gram(dev, K, D):
+    U = make(K, D, dev)
+    G = ops.gram(U)
+    R = (U.double() @ U.double().t()).float()
+    torch.testing.assert_close(G, R, rtol=1e-4, atol=1e-3 * max(1.0, D ** 0.5 / 10))
+    # asymmetric check: G must equal its transpose exactly where mirrored, and the
+    # diagonal must match row norms
+    assert torch.equal(G, G.t()) or torch.allclose(G, G.t(), rtol=0, atol=1e-4)
+
+
+def test_gram_identical_rows_cancel_exactly(dev):
+    U = make(300, 9000, dev)
+    U[5] = U[200]
+    U[17] = U[5]
+    G = ops.gram(U)
+    d = G[5, 5] + G[200, 200] - 2 * G[5, 200]
+    assert float(d) == 0.0
+    assert float(G[17, 17] + G[5, 5] - 2 * G[17, 5]) == 0.0
+
+
+def test_row_scale_set_rows_forge(dev):
+    K, D = 60, 5003
+    U = make(K, D, dev)
+    s = torch.rand(K, device=dev)
+    s[::3] = 1.0
+    exp = U * s[:, None]
+    ops.row_scale_(U, s)
+    torch.testing.assert_close(U, exp)
+    v = torch.randn(D, device=dev)
+    rows = torch.tensor([0, 5, 59])
+    ops.set_rows_(U, rows, v)
+    assert torch.equal(U[5], v) and torch.equal(U[59], v)
+    # ALIE / IPM fused
+    U = make(K, D, dev, seed=3)
+    mask = torch.ones(K, device=dev)
+    mask[:12] = 0
+    mal = torch.arange(12, device=dev)
+    sign = torch.where(torch.arange(D, device=dev) < D // 2, -1.0, 1.0)
+    U2 = U.clone()
+    v = ops.alie_forge_(U, mask, mal, 0.7, sign)
+    v2 = ref.alie_forge_(U2, mask, mal, 0.7, sign)
+    torch.testing.assert_close(v, v2, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(U, U2, rtol=1e-4, atol=1e-5)
+    v = ops.ipm_forge_(U, mask, mal, 100.0)
+    v2 = ref.ipm_forge_(U2, mask, mal, 100.0)
+    torch.testing.assert_close(U, U2, rtol=1e-4, atol=1e-3)
+
+
+def test_optimizer_steps(dev):
+    n = 100003
+    th = torch.randn(n, device=dev)
+    agg = torch.randn(n, device=dev)
+    for mu in (0.0, 0.9):
+        a, b = th.clone(), th.clone()
+        ba, bb = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        for first in (True, False):
+            ops.server_step_(a, ba, agg, 0.1, mu, first)
+            ref.server_step_(b, bb, agg, 0.1, mu, first)
+        torch.testing.assert_close(a, b)
+    Kc, D = 7, 3001
+    for mu in (0.0, 0.5):
+        W = torch.randn(Kc, D, device=dev)
+        G = torch.randn(Kc, D, device=dev)
+        gs = torch.tensor([1, -1, 0.5, 1, 1, 2, 1.0], device=dev)
+        W2, M, M2 = W.clone(), torch.zeros(Kc, D, device=dev), torch.zeros(Kc, D, device=dev)
+        for first in (True, False):
+            ops.client_sgd_step_(W, G, M, 0.3, mu, first, gs)
+            ref.client_sgd_step_(W2, G, M2, 0.3, mu, first, gs)
+        torch.testing.assert_close(W, W2)
+
+
+def test_philox_matches_reference(dev):
+    for off in (0, 5, 2 ** 33 + 3):
+        u = ops.philox_uniform(1000, 1234, 7, off, device=dev)
+        r = ref.philox_uniform(1000, 1234, 7, off)
+        assert torch.equal(u.cpu(), r)
+        z = ops.philox_normal(1000, 99, 3, off, 0.1, 0.5, device=dev)
+        rz = ref.philox_normal(1000, 99, 3, off, 0.1, 0.5)
+        torch.testing.assert_close(z.cpu(), rz, rtol=1e-4, atol=1e-5)
+    U = torch.zeros(4, 1001, device=dev)
+    R = torch.zeros(4, 1001)
+    rows = torch.tensor([[1, 11], [3, 2]])
+    ops.add_normal_rows_(U, rows, 5, 9, 100, 5000, 0.1, 0.2, True)
+    ref.add_normal_rows_(R, rows, 5, 9, 100, 5000, 0.1, 0.2, True)
+    torch.testing.assert_close(U.cpu(), R, rtol=1e-4, atol=1e-5)
+    assert abs(float(U[1].mean()) - 0.1) < 0.03 and abs(float(U[1].std()) - 0.2) < 0.03
+
+
+def test_augment_matches_reference(dev):
+    from blades_amd.datasets.transforms import BatchAugment
+
+    aug = BatchAugment(32, (0.75, 1.0), 0.5, (0.49, 0.48, 0.44), (0.2, 0.2, 0.2), erase_p=0.5)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(6, 8, 3, 32, 32, generator=g)
+    p = aug.draw(6, g)
+    r = aug.apply_reference(x, p)
+    o = aug.apply(x.to(dev), p)
+    torch.testing.assert_close(o.cpu(), r, rtol=1e-4, atol=1e-4)
