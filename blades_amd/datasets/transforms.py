@@ -77,7 +77,9 @@ class BatchAugment:
     def apply(self, x: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
         """``x``: [n, B, C, H, W] float; ``params``: [n, N_PARAMS]."""
         if x.is_cuda:
-            from blades_amd.ops import _hip
+            from blades_amd import ops
+
+            _hip = ops._h()
 
             mean = self.normalize.mean if self.normalize else (0.0,) * x.shape[2]
             std = self.normalize.std if self.normalize else (1.0,) * x.shape[2]

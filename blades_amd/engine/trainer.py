@@ -33,6 +33,7 @@ from torch.func import functional_call, grad_and_value, vmap
 from blades_amd import ops
 from blades_amd.constants import CLIENT_UPDATE
 from blades_amd.parallel.context import ShardContext, padded_width
+from .layers import make_engine_model
 from .plan import RowPlan, make_plan
 from .sampler import DeviceSampler
 
@@ -53,7 +54,7 @@ class ClientEngine:
                  amp_dtype="auto", execution_mode: str = "auto", num_classes: Optional[int] = None,
                  eval_clients_per_chunk: Optional[int] = None):
         self.task = task
-        self.model = task.model
+        self.model = make_engine_model(task.model)
         self.dataset = dataset
         self.clients = clients
         self.rt = runtime
@@ -74,8 +75,8 @@ class ClientEngine:
         self.round = 0
 
         # ---- parameter layout (named_parameters order == reference flattening)
-        self.names = [n for n, _ in self.model.named_parameters()]
-        self.shapes = [tuple(p.shape) for _, p in self.model.named_parameters()]
+        self.names = [n for n, _ in task.model.named_parameters()]
+        self.shapes = [tuple(p.shape) for _, p in task.model.named_parameters()]
         self.numels = [int(np.prod(s)) if len(s) else 1 for s in self.shapes]
         self.offsets = np.concatenate([[0], np.cumsum(self.numels)]).astype(np.int64)
         self.D = int(self.offsets[-1])

@@ -18,10 +18,17 @@ def _use_hip(t: torch.Tensor) -> bool:
     return t.is_cuda and not _FORCE_REFERENCE
 
 
-def _hip():
-    from . import _hip as h  # noqa: WPS433 (lazy: ctypes load)
+_hip_module = None
 
-    return h
+
+def _h():
+    """The ctypes kernel module (lazy import: loading it needs the built .so)."""
+    global _hip_module
+    if _hip_module is None:
+        import importlib
+
+        _hip_module = importlib.import_module("blades_amd.ops._hip")
+    return _hip_module
 
 
 class force_reference:
@@ -45,7 +52,7 @@ def _f32c(U):
 
 def weighted_col_sum(U, w):
     if _use_hip(_f32c(U)):
-        return _hip().weighted_col_sum(U, w)
+        return _h().weighted_col_sum(U, w)
     return ref.weighted_col_sum(U, w)
 
 
@@ -57,25 +64,25 @@ def col_mean(U, mask=None):
         else:
             m = mask.to(device=U.device, dtype=torch.float32)
             w = m / m.sum()
-        return _hip().weighted_col_sum(U, w)
+        return _h().weighted_col_sum(U, w)
     return ref.col_mean(U, mask)
 
 
 def col_mean_std(U, mask=None):
     if _use_hip(_f32c(U)):
-        return _hip().col_mean_std(U, mask)
+        return _h().col_mean_std(U, mask)
     return ref.col_mean_std(U, mask)
 
 
 def col_min_max(U, mask=None):
     if _use_hip(_f32c(U)):
-        return _hip().col_min_max(U, mask)
+        return _h().col_min_max(U, mask)
     return ref.col_min_max(U, mask)
 
 
 def col_median(U, mask=None):
     if _use_hip(_f32c(U)):
-        return _hip().col_order_stat(U, mask, 0, 0)
+        return _h().col_order_stat(U, mask, 0, 0)
     return ref.col_median(U, mask)
 
 
@@ -84,91 +91,91 @@ def col_trimmed_mean(U, b, mask=None):
     if n <= 2 * b:
         raise ValueError("Not enough inputs to compute trimmed mean")
     if _use_hip(_f32c(U)):
-        return _hip().col_order_stat(U, mask, 1, int(b))
+        return _h().col_order_stat(U, mask, 1, int(b))
     return ref.col_trimmed_mean(U, b, mask)
 
 
 def row_stats(U, valid_cols=None):
     if _use_hip(_f32c(U)):
-        return _hip().row_stats(U, U.shape[1] if valid_cols is None else int(valid_cols))
+        return _h().row_stats(U, U.shape[1] if valid_cols is None else int(valid_cols))
     return ref.row_stats(U, valid_cols)
 
 
 def row_sqnorm(U):
     if _use_hip(_f32c(U)):
-        return _hip().row_stats(U, U.shape[1], counts=False)[0]
+        return _h().row_stats(U, U.shape[1], counts=False)[0]
     return ref.row_sqnorm(U)
 
 
 def sqdist_to(U, m):
     if _use_hip(_f32c(U)):
-        return _hip().sqdist_to(U, m)
+        return _h().sqdist_to(U, m)
     return ref.sqdist_to(U, m)
 
 
 def row_dot(U, v):
     if _use_hip(_f32c(U)):
-        return _hip().row_dot(U, v)
+        return _h().row_dot(U, v)
     return ref.row_dot(U, v)
 
 
 def gram(U):
     if _use_hip(_f32c(U)):
-        return _hip().gram(U)
+        return _h().gram(U)
     return ref.gram(U)
 
 
 def row_scale_(U, s):
     if _use_hip(_f32c(U)):
-        return _hip().row_scale_(U, s)
+        return _h().row_scale_(U, s)
     return ref.row_scale_(U, s)
 
 
 def set_rows_(U, rows, v):
     if _use_hip(_f32c(U)) and v.dim() == 1:
-        return _hip().set_rows_(U, rows, v)
+        return _h().set_rows_(U, rows, v)
     return ref.set_rows_(U, rows, v)
 
 
 def alie_forge_(U, benign_mask, mal_rows, z, sign=None):
     if _use_hip(_f32c(U)):
-        return _hip().alie_forge_(U, benign_mask, mal_rows, float(z), sign)
+        return _h().alie_forge_(U, benign_mask, mal_rows, float(z), sign)
     return ref.alie_forge_(U, benign_mask, mal_rows, z, sign)
 
 
 def ipm_forge_(U, benign_mask, mal_rows, scale):
     if _use_hip(_f32c(U)):
-        return _hip().ipm_forge_(U, benign_mask, mal_rows, float(scale))
+        return _h().ipm_forge_(U, benign_mask, mal_rows, float(scale))
     return ref.ipm_forge_(U, benign_mask, mal_rows, scale)
 
 
 def server_step_(theta, buf, agg, lr, momentum, first):
     if theta.is_cuda and not _FORCE_REFERENCE:
-        return _hip().server_step_(theta, buf, agg, float(lr), float(momentum), bool(first))
+        return _h().server_step_(theta, buf, agg, float(lr), float(momentum), bool(first))
     return ref.server_step_(theta, buf, agg, lr, momentum, first)
 
 
 def client_sgd_step_(W, G, M, lr, momentum, first, gscale=None):
     if W.is_cuda and not _FORCE_REFERENCE:
-        return _hip().client_sgd_step_(W, G, M, float(lr), float(momentum), bool(first), gscale)
+        return _h().client_sgd_step_(W, G, M, float(lr), float(momentum), bool(first), gscale)
     return ref.client_sgd_step_(W, G, M, lr, momentum, first, gscale)
 
 
 def philox_uniform(n, seed, stream, offset=0, device="cpu"):
     if torch.device(device).type == "cuda" and not _FORCE_REFERENCE:
-        return _hip().philox_uniform(n, seed, stream, offset, device)
+        return _h().philox_uniform(n, seed, stream, offset, device)
     return ref.philox_uniform(n, seed, stream, offset, device)
 
 
 def philox_normal(n, seed, stream, offset=0, mean=0.0, std=1.0, device="cpu"):
     if torch.device(device).type == "cuda" and not _FORCE_REFERENCE:
-        return _hip().philox_normal(n, seed, stream, offset, mean, std, device)
+        return _h().philox_normal(n, seed, stream, offset, mean, std, device)
     return ref.philox_normal(n, seed, stream, offset, mean, std, device)
 
 
 def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite):
     if _use_hip(_f32c(U)):
-        return _hip().add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite)
+        return _h().add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite)
     return ref.add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite)
 
 

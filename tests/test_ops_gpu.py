@@ -12,7 +12,7 @@ from blades_amd.ops import reference as ref
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "gpu tests need a GPU"
-    from blades_amd.ops import _hip  # noqa: F401  (must load: no fallback on GPU)
+    import importlib; importlib.import_module('blades_amd.ops._hip')  # must load: no fallback on GPU
 
     return torch.device("cuda")
 
