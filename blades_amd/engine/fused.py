@@ -1,0 +1,282 @@
+"""Shared-weight / per-client-gradient executor (the FedSGD fast path).
+
+When every client of a chunk starts the round from the same weights (one local
+step), forward and the data-gradient pass are ordinary big-batch ops over
+``[Kc*B, ...]`` with *shared* weights; only two things are per client:
+
+* normalisation statistics — ``PCBatchNorm2d`` reduces over one client's
+  ``(B, H, W)`` only;
+* parameter gradients — ``dW_c = X_c^T dY_c`` for each client, a grouped
+  GEMM / grouped conv-wgrad whose result is written (scaled by ``-lr`` and the
+  client's sign/clip coefficient) straight into row ``c`` of the update matrix.
+
+No per-client weight copy is ever made.  The model is
+executed through a *template* whose ``Conv2d`` / ``Linear`` / ``BatchNorm2d``
+leaves are replaced by the ``PC*`` layers below; any other parameterised layer
+makes ``supports()`` return False and the engine falls back to the generic
+vectorised path.
+
+Samples are ordered client-major (index = ``c*B + b``); 4-D activations are
+channels-last, bf16 (or the engine's amp dtype); reductions and the per-client
+gradients are fp32.
+"""
+import copy
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class GradSink:
+    """Routes per-client parameter gradients into rows of the update matrix."""
+
+    def __init__(self):
+        self.block: Optional[torch.Tensor] = None  # [Kc, >=D] view of U_row rows (row stride = ld)
+        self.scale: Optional[torch.Tensor] = None  # [Kc] fp32 coefficient per client (e.g. -lr * sign)
+        self.Kc = 0
+        self.B = 0
+        self.offsets: Dict[int, tuple] = {}  # id(param) -> (offset, numel)
+        self._written = set()
+
+    def begin(self, block, scale, Kc, B):
+        self.block, self.scale, self.Kc, self.B = block, scale, Kc, B
+        self._written = set()
+
+    def view(self, param) -> torch.Tensor:
+        off, n = self.offsets[id(param)]
+        return self.block[:, off: off + n]
+
+    def write(self, param, g: torch.Tensor):
+        """``g``: [Kc, *param.shape] (any float dtype) -> scaled fp32 row slices."""
+        v = self.view(param)
+        g = g.reshape(self.Kc, -1)
+        if id(param) in self._written:  # a parameter used twice in the forward pass
+            v.add_(g.float() * self.scale.unsqueeze(1))
+        else:
+            torch.mul(g.float(), self.scale.unsqueeze(1), out=v)
+            self._written.add(id(param))
+
+
+# ---------------------------------------------------------------------------
+class _PCConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, mod):
+        w = weight.to(x.dtype)
+        b = mod.bias.to(x.dtype) if mod.bias is not None else None
+        ctx.mod = mod
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, b, mod.stride, mod.padding, mod.dilation, 1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        mod = ctx.mod
+        sink: GradSink = mod.sink
+        Kc, B = sink.Kc, sink.B
+        gy = gy.contiguous(memory_format=torch.channels_last) if gy.dim() == 4 else gy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(
+                gy, x, w, None, mod.stride, mod.padding, mod.dilation, False, [0, 0], 1, [True, False, False])[0]
+        dw = mod.wgrad(x, gy, Kc, B)  # [Kc, Cout, Cin, kh, kw] fp32 (or None if written in place)
+        if dw is not None:
+            sink.write(mod.weight, dw)
+        if mod.bias is not None:
+            sink.write(mod.bias, gy.float().reshape(Kc, B, gy.shape[1], -1).sum(dim=(1, 3)))
+        return dx, None, None
+
+
+class PCConv2d(nn.Module):
+    def __init__(self, conv: nn.Conv2d, sink: GradSink):
+        super().__init__()
+        assert conv.groups == 1 and conv.padding_mode == "zeros"
+        self.weight, self.bias = conv.weight, conv.bias
+        self.stride, self.padding, self.dilation = list(conv.stride), list(conv.padding), list(conv.dilation)
+        self.sink = sink
+
+    def forward(self, x):
+        return _PCConvFn.apply(x, self.weight, self)
+
+    def wgrad(self, x, gy, Kc, B):
+        """Per-client weight gradient.  Reference implementation: regroup to
+        ``[B, Kc*C, H, W]`` and use the grouped-conv weight-gradient (one group per
+        client).  The HIP kernel (ops/csrc/conv_wgrad.hip) replaces this on the GPU."""
+        N, Ci, H, W = x.shape
+        Co = gy.shape[1]
+        xg = x.reshape(Kc, B, Ci, H, W).transpose(0, 1).reshape(B, Kc * Ci, H, W)
+        gg = gy.reshape(Kc, B, Co, gy.shape[2], gy.shape[3]).transpose(0, 1).reshape(B, Kc * Co, gy.shape[2],
+                                                                                     gy.shape[3])
+        if x.is_cuda:
+            xg = xg.contiguous(memory_format=torch.channels_last)
+            gg = gg.contiguous(memory_format=torch.channels_last)
+        wshape = [Kc * Co, Ci, self.weight.shape[2], self.weight.shape[3]]
+        wfake = x.new_empty(wshape)
+        dw = torch.ops.aten.convolution_backward(
+            gg, xg, wfake, None, self.stride, self.padding, self.dilation, False, [0, 0], Kc,
+            [False, True, False])[1]
+        return dw.reshape(Kc, Co, Ci, self.weight.shape[2], self.weight.shape[3])
+
+
+class _PCLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, mod):
+        w = weight.to(x.dtype)
+        ctx.mod = mod
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w, mod.bias.to(x.dtype) if mod.bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        mod = ctx.mod
+        sink: GradSink = mod.sink
+        Kc = sink.Kc
+        dx = gy @ w if ctx.needs_input_grad[0] else None
+        g3 = gy.reshape(Kc, -1, gy.shape[-1])  # [Kc, B*, out]
+        x3 = x.reshape(Kc, -1, x.shape[-1])  # [Kc, B*, in]
+        sink.write(mod.weight, torch.bmm(g3.transpose(1, 2), x3))
+        if mod.bias is not None:
+            sink.write(mod.bias, g3.float().sum(dim=1))
+        return dx, None, None
+
+
+class PCLinear(nn.Module):
+    def __init__(self, lin: nn.Linear, sink: GradSink):
+        super().__init__()
+        self.weight, self.bias, self.sink = lin.weight, lin.bias, sink
+
+    def forward(self, x):
+        return _PCLinearFn.apply(x, self.weight, self)
+
+
+class _PCBatchNormFn(torch.autograd.Function):
+    """Per-client batch-statistics BN.  x: [Kc*B, C, H, W]; stats over (B, H, W)
+    of each client.  fp32 math, output in x's dtype.  (Reference implementation
+    in torch ops; the fused HIP kernels in ops/csrc/pcbn.hip replace it on GPU.)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, mod):
+        sink: GradSink = mod.sink
+        Kc, B = sink.Kc, sink.B
+        N, C, H, W = x.shape
+        xf = x.float().reshape(Kc, B, C, H, W)
+        var, mean = torch.var_mean(xf, dim=(1, 3, 4), unbiased=False, keepdim=True)
+        invstd = torch.rsqrt(var + mod.eps)
+        xhat = (xf - mean) * invstd
+        y = xhat
+        if mod.weight is not None:
+            y = xhat * mod.weight.float().view(1, 1, C, 1, 1) + mod.bias.float().view(1, 1, C, 1, 1)
+        ctx.mod = mod
+        ctx.save_for_backward(x, mean, invstd)
+        out = y.reshape(N, C, H, W).to(x.dtype)
+        return out.contiguous(memory_format=torch.channels_last) if x.is_cuda else out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, invstd = ctx.saved_tensors
+        mod = ctx.mod
+        sink: GradSink = mod.sink
+        Kc, B = sink.Kc, sink.B
+        N, C, H, W = x.shape
+        g = gy.float().reshape(Kc, B, C, H, W)
+        xhat = (x.float().reshape(Kc, B, C, H, W) - mean) * invstd
+        dbeta = g.sum(dim=(1, 3, 4))  # [Kc, C]
+        dgamma = (g * xhat).sum(dim=(1, 3, 4))
+        if mod.weight is not None:
+            sink.write(mod.weight, dgamma)
+            sink.write(mod.bias, dbeta)
+            gw = g * mod.weight.float().view(1, 1, C, 1, 1)
+            s1 = dbeta * mod.weight.float().view(1, C)
+            s2 = dgamma * mod.weight.float().view(1, C)
+        else:
+            gw, s1, s2 = g, dbeta, dgamma
+        m = float(B * H * W)
+        dx = (gw - s1.view(Kc, 1, C, 1, 1) / m - xhat * s2.view(Kc, 1, C, 1, 1) / m) * invstd
+        dx = dx.reshape(N, C, H, W).to(x.dtype)
+        return (dx.contiguous(memory_format=torch.channels_last) if x.is_cuda else dx), None, None
+
+
+class PCBatchNorm2d(nn.Module):
+    def __init__(self, bn: nn.BatchNorm2d, sink: GradSink):
+        super().__init__()
+        self.eps = bn.eps
+        self.weight = bn.weight if bn.affine else None
+        self.bias = bn.bias if bn.affine else None
+        self.sink = sink
+
+    def forward(self, x):
+        return _PCBatchNormFn.apply(x, self.weight if self.weight is not None else x, self)
+
+
+# ---------------------------------------------------------------------------
+def supports(model: nn.Module) -> bool:
+    """True iff every parameterised leaf is a layer the fused executor handles."""
+    for m in model.modules():
+        own = list(m.parameters(recurse=False))
+        if not own:
+            continue
+        if isinstance(m, nn.Conv2d) and m.groups == 1 and m.padding_mode == "zeros" and not isinstance(
+                m.padding, str):
+            continue
+        if isinstance(m, nn.Linear):
+            continue
+        if isinstance(m, nn.BatchNorm2d) and not m.track_running_stats:
+            continue
+        return False
+    return True
+
+
+def build_template(model: nn.Module, sink: GradSink) -> nn.Module:
+    memo = {id(p): p for p in model.parameters()}
+    tmpl = copy.deepcopy(model, memo)
+
+    def swap(mod):
+        for name, child in list(mod.named_children()):
+            if isinstance(child, nn.Conv2d):
+                setattr(mod, name, PCConv2d(child, sink))
+            elif isinstance(child, nn.Linear):
+                setattr(mod, name, PCLinear(child, sink))
+            elif isinstance(child, nn.BatchNorm2d):
+                setattr(mod, name, PCBatchNorm2d(child, sink))
+            else:
+                swap(child)
+
+    swap(tmpl)
+    return tmpl
+
+
+class FusedFedSGD:
+    """Runs one shared-weight forward/backward for a chunk of clients and leaves
+    ``scale_c * dL_c/dtheta`` in the chunk's rows of the update matrix."""
+
+    def __init__(self, task, names, offsets, numels, amp_dtype, device):
+        self.task = task
+        self.sink = GradSink()
+        self.template = build_template(task.model, self.sink)
+        for (n, p), o, m in zip(task.model.named_parameters(), offsets[:-1], numels):
+            self.sink.offsets[id(p)] = (int(o), int(m))
+        self.amp_dtype = amp_dtype
+        self.device = device
+
+    def run(self, X: torch.Tensor, Y: torch.Tensor, block: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+        """X [Kc, B, ...], Y [Kc, B]; ``block`` = the chunk's rows of U (row stride
+        preserved); returns per-client losses [Kc] (fp32, detached)."""
+        Kc, B = Y.shape
+        self.sink.begin(block, scale, Kc, B)
+        x = X.reshape(Kc * B, *X.shape[2:])
+        if self.amp_dtype is not None:
+            x = x.to(self.amp_dtype)
+        if x.dim() == 4 and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
+        self.template.train()
+        # the input needs no gradient: first-layer backward skips its dgrad
+        logits = self.template(x)
+        lg = logits.float().reshape(Kc, B, -1)
+        losses = torch.vmap(lambda z, y: self.task.loss(_identity, z, y))(lg, Y)
+        losses.sum().backward()
+        return losses.detach()
+
+
+def _identity(z):
+    return z

@@ -110,6 +110,11 @@ class ClientEngine:
                                                             device=self.device)
         self.M = None  # per-client momentum buffers [Kloc_train, D], lazily
         self._mom_init = False
+        from . import fused
+
+        self.fused = None
+        if self.mode in ("auto", "batched", "fused") and fused.supports(task.model):
+            self.fused = fused.FusedFedSGD(task, self.names, self.offsets, self.numels, self.amp_dtype, self.device)
 
     # ------------------------------------------------------------------
     def refresh_client_specs(self):
@@ -184,25 +189,41 @@ class ClientEngine:
     def _train_chunk_fedsgd(self, theta, rows, srows):
         gscale, flip, gclip = self._row_vectors(rows)
         X, Y = self._fetch_batch(srows, flip)
-        grads, losses = self._grads(self._params_from_flat(theta), X, Y, per_client_params=False)
-        G = torch.empty(len(rows), self.D, device=self.device)
-        self._flatten_into(grads, G)
-        del grads
+        rows_t = torch.as_tensor(rows, device=self.device)
+        contiguous = int(rows[-1] - rows[0]) == len(rows) - 1
+        plain = self.momentum == 0.0 and not bool(torch.isfinite(gclip).any())
+        if self.fused is not None:
+            # per-client gradients land in the rows of U directly, pre-scaled
+            block = self.U_row[int(rows[0]): int(rows[-1]) + 1] if contiguous else torch.empty(
+                len(rows), self.D, device=self.device)
+            scale = (-self.lr * gscale) if plain else torch.ones_like(gscale)
+            losses = self.fused.run(X, Y, block, scale.float())
+            if plain:
+                if not contiguous:
+                    self.U_row[rows_t, : self.D] = block
+                return losses
+            G = block[:, : self.D]
+        else:
+            grads, losses = self._grads(self._params_from_flat(theta), X, Y, per_client_params=False)
+            G = torch.empty(len(rows), self.D, device=self.device)
+            self._flatten_into(grads, G)
+            del grads
+            contiguous = False
         if bool(torch.isfinite(gclip).any()):
             gscale = gscale * self._clip_coef(ops.row_sqnorm(G), gclip)
-        rows_t = torch.as_tensor(rows, device=self.device)
         if self.momentum != 0.0:
             if self.M is None:
                 self.M = torch.zeros(len(self._train_rows), self.D, device=self.device)
             srows_t = torch.as_tensor(srows, device=self.device)
             Mv = self.M[srows_t]
-            W = torch.zeros_like(G)  # W - 0 = update after one fused step from zero
+            W = torch.zeros(len(rows), self.D, device=self.device)  # W - 0 = update after one step from zero
             ops.client_sgd_step_(W, G, Mv, self.lr, self.momentum, not self._mom_init, gscale)
             self.M[srows_t] = Mv
-            G = W
+            self.U_row[rows_t, : self.D] = W
         else:
             ops.row_scale_(G, -self.lr * gscale)
-        self.U_row[rows_t, : self.D] = G
+            if not (self.fused is not None and contiguous):
+                self.U_row[rows_t, : self.D] = G
         return losses
 
     def _train_chunk_general(self, theta, rows, srows):
