@@ -150,51 +150,102 @@ class PCLinear(nn.Module):
         return _PCLinearFn.apply(x, self.weight, self)
 
 
+def _bn_forward_ref(x, res, gamma, beta, Kc, eps, relu):
+    N, C, H, W = x.shape
+    B = N // Kc
+    xf = x.float().reshape(Kc, B, C, H, W)
+    var, mean = torch.var_mean(xf, dim=(1, 3, 4), unbiased=False, keepdim=True)
+    invstd = torch.rsqrt(var + eps)
+    y = (xf - mean) * invstd
+    if gamma is not None:
+        y = y * gamma.float().view(1, 1, C, 1, 1) + beta.float().view(1, 1, C, 1, 1)
+    y = y.reshape(N, C, H, W)
+    if res is not None:
+        y = y + res.float()
+    if relu:
+        y = torch.relu(y)
+    y = y.to(x.dtype)
+    if x.is_cuda:
+        y = y.contiguous(memory_format=torch.channels_last)
+    return y, mean.reshape(Kc, C), invstd.reshape(Kc, C)
+
+
+def _bn_backward_ref(x, gy, y, gamma, mean, invstd, Kc, relu, want_gres):
+    N, C, H, W = x.shape
+    B = N // Kc
+    g = gy.float()
+    if relu:
+        g = g * (y > 0)
+    g5 = g.reshape(Kc, B, C, H, W)
+    xhat = (x.float().reshape(Kc, B, C, H, W) - mean.view(Kc, 1, C, 1, 1)) * invstd.view(Kc, 1, C, 1, 1)
+    dbeta = g5.sum(dim=(1, 3, 4))
+    dgamma = (g5 * xhat).sum(dim=(1, 3, 4))
+    gam = gamma.float().view(1, C) if gamma is not None else torch.ones(1, C, device=x.device)
+    m = float(B * H * W)
+    dx = (gam * invstd).view(Kc, 1, C, 1, 1) * (g5 - (dbeta / m).view(Kc, 1, C, 1, 1)
+                                               - xhat * (dgamma / m).view(Kc, 1, C, 1, 1))
+    dx = dx.reshape(N, C, H, W).to(x.dtype)
+    gres = g.to(x.dtype) if want_gres else None
+    if x.is_cuda:
+        dx = dx.contiguous(memory_format=torch.channels_last)
+        if gres is not None:
+            gres = gres.contiguous(memory_format=torch.channels_last)
+    return dx, gres, dgamma, dbeta
+
+
 class _PCBatchNormFn(torch.autograd.Function):
-    """Per-client batch-statistics BN.  x: [Kc*B, C, H, W]; stats over (B, H, W)
-    of each client.  fp32 math, output in x's dtype.  (Reference implementation
-    in torch ops; the fused HIP kernels in ops/csrc/pcbn.hip replace it on GPU.)"""
+    """Per-client batch-statistics BN with fused residual add and ReLU.
+
+    x (and residual): [Kc*B, C, H, W]; statistics over one client's (B, H, W).
+    GPU bf16 channels-last inputs run the HIP kernels of ops/csrc/pcbn.hip (which also write
+    the per-client dgamma/dbeta straight into the update-matrix rows); everything else runs the
+    torch reference above."""
 
     @staticmethod
-    def forward(ctx, x, anchor, mod):
+    def forward(ctx, x, res, anchor, mod, relu):
         sink: GradSink = mod.sink
-        Kc, B = sink.Kc, sink.B
-        N, C, H, W = x.shape
-        xf = x.float().reshape(Kc, B, C, H, W)
-        var, mean = torch.var_mean(xf, dim=(1, 3, 4), unbiased=False, keepdim=True)
-        invstd = torch.rsqrt(var + mod.eps)
-        xhat = (xf - mean) * invstd
-        y = xhat
-        if mod.weight is not None:
-            y = xhat * mod.weight.float().view(1, 1, C, 1, 1) + mod.bias.float().view(1, 1, C, 1, 1)
-        ctx.mod = mod
-        ctx.save_for_backward(x, mean, invstd)
-        out = y.reshape(N, C, H, W).to(x.dtype)
-        return out.contiguous(memory_format=torch.channels_last) if x.is_cuda else out
+        Kc = sink.Kc
+        use_hip = x.is_cuda and _hipmod().pcbn_supported(x) and (res is None or _hipmod().pcbn_supported(res))
+        if use_hip:
+            y, mean, invstd = _hipmod().pcbn_forward(x, res, mod.weight, mod.bias, Kc, mod.eps, relu)
+        else:
+            y, mean, invstd = _bn_forward_ref(x, res, mod.weight, mod.bias, Kc, mod.eps, relu)
+        ctx.mod, ctx.relu, ctx.has_res, ctx.use_hip = mod, relu, res is not None, use_hip
+        ctx.save_for_backward(x, y if relu else None, mean, invstd)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, mean, invstd = ctx.saved_tensors
+        x, y, mean, invstd = ctx.saved_tensors
         mod = ctx.mod
         sink: GradSink = mod.sink
-        Kc, B = sink.Kc, sink.B
-        N, C, H, W = x.shape
-        g = gy.float().reshape(Kc, B, C, H, W)
-        xhat = (x.float().reshape(Kc, B, C, H, W) - mean) * invstd
-        dbeta = g.sum(dim=(1, 3, 4))  # [Kc, C]
-        dgamma = (g * xhat).sum(dim=(1, 3, 4))
-        if mod.weight is not None:
-            sink.write(mod.weight, dgamma)
-            sink.write(mod.bias, dbeta)
-            gw = g * mod.weight.float().view(1, 1, C, 1, 1)
-            s1 = dbeta * mod.weight.float().view(1, C)
-            s2 = dgamma * mod.weight.float().view(1, C)
+        Kc = sink.Kc
+        want_gres = ctx.has_res and ctx.relu
+        if ctx.use_hip:
+            gy = gy.contiguous(memory_format=torch.channels_last)
+            U, offg, offb, acc = None, 0, 0, False
+            if mod.weight is not None:
+                U = sink.block
+                offg, offb = sink.offsets[id(mod.weight)][0], sink.offsets[id(mod.bias)][0]
+                acc = id(mod.weight) in sink._written
+                sink._written.add(id(mod.weight))
+                sink._written.add(id(mod.bias))
+            dx, gres = _hipmod().pcbn_backward(x, gy, y, mod.weight, mean, invstd, Kc, sink.scale, U, offg, offb,
+                                               acc, want_gres)
         else:
-            gw, s1, s2 = g, dbeta, dgamma
-        m = float(B * H * W)
-        dx = (gw - s1.view(Kc, 1, C, 1, 1) / m - xhat * s2.view(Kc, 1, C, 1, 1) / m) * invstd
-        dx = dx.reshape(N, C, H, W).to(x.dtype)
-        return (dx.contiguous(memory_format=torch.channels_last) if x.is_cuda else dx), None, None
+            dx, gres, dgamma, dbeta = _bn_backward_ref(x, gy, y, mod.weight, mean, invstd, Kc, ctx.relu, want_gres)
+            if mod.weight is not None:
+                sink.write(mod.weight, dgamma)
+                sink.write(mod.bias, dbeta)
+        if ctx.has_res and not ctx.relu:
+            gres = gy
+        return dx, (gres if ctx.has_res else None), None, None, None
+
+
+def _hipmod():
+    from blades_amd import ops
+
+    return ops._h()
 
 
 class PCBatchNorm2d(nn.Module):
@@ -205,8 +256,42 @@ class PCBatchNorm2d(nn.Module):
         self.bias = bn.bias if bn.affine else None
         self.sink = sink
 
+    def forward(self, x, residual=None, relu: bool = False):
+        anchor = self.weight if self.weight is not None else x
+        return _PCBatchNormFn.apply(x, residual, anchor, self, relu)
+
+
+class PCResBlock(nn.Module):
+    """BasicBlock / Bottleneck of models/resnet.py with BN+ReLU and BN+add+ReLU fused."""
+
+    def __init__(self, blk):
+        super().__init__()
+        self.blk = blk
+        self.bottleneck = hasattr(blk, "conv3")
+
     def forward(self, x):
-        return _PCBatchNormFn.apply(x, self.weight if self.weight is not None else x, self)
+        b = self.blk
+        sc = x
+        if len(b.shortcut) > 0:
+            sc = b.shortcut[1](b.shortcut[0](x))
+        out = b.bn1(b.conv1(x), relu=True)
+        if self.bottleneck:
+            out = b.bn2(b.conv2(out), relu=True)
+            return b.bn3(b.conv3(out), residual=sc, relu=True)
+        return b.bn2(b.conv2(out), residual=sc, relu=True)
+
+
+class PCResNet(nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, x):
+        n = self.net
+        out = n.bn1(n.conv1(x), relu=True)
+        out = n.layer4(n.layer3(n.layer2(n.layer1(out))))
+        out = F.avg_pool2d(out, 4)
+        return n.linear(out.reshape(out.size(0), -1))
 
 
 # ---------------------------------------------------------------------------
@@ -243,6 +328,13 @@ def build_template(model: nn.Module, sink: GradSink) -> nn.Module:
                 swap(child)
 
     swap(tmpl)
+    from blades_amd.models import resnet as _rn
+
+    if isinstance(tmpl, _rn.ResNet):
+        for stage in (tmpl.layer1, tmpl.layer2, tmpl.layer3, tmpl.layer4):
+            for i, blk in enumerate(list(stage)):
+                stage[i] = PCResBlock(blk)
+        tmpl = PCResNet(tmpl)
     return tmpl
 
 

@@ -24,7 +24,7 @@ class DeviceSampler:
         self.device = device
         self.K = len(self.n)
         self.nmax = int(self.n.max()) if self.K else 0
-        self.gen = torch.Generator(device=device)
+        self.gen = torch.Generator()  # CPU generator: the same permutations on every device type
         self.gen.manual_seed(int(seed))
         self.cursor = np.zeros(self.K, dtype=np.int64)
         self.perm = torch.zeros(self.K, max(self.nmax, 1), dtype=torch.int64, device=device)
@@ -34,7 +34,7 @@ class DeviceSampler:
 
     def _reshuffle(self, rows: np.ndarray):
         r = torch.as_tensor(rows, device=self.device)
-        keys = torch.rand(len(rows), self.nmax, generator=self.gen, device=self.device)
+        keys = torch.rand(len(rows), self.nmax, generator=self.gen).to(self.device)
         invalid = torch.arange(self.nmax, device=self.device).unsqueeze(0) >= self.n_t[r].unsqueeze(1)
         keys.masked_fill_(invalid, 2.0)
         self.perm[r] = keys.argsort(dim=1)

@@ -73,6 +73,12 @@ class ClientEngine:
         self.amp_dtype = _DTYPES[amp_dtype] if not isinstance(amp_dtype, torch.dtype) else amp_dtype
         self.timers: Dict[str, float] = {}
         self.round = 0
+        if self.device.type == "cuda":
+            # MIOpen "find" mode: without it the immediate-mode fallback picks the naive
+            # direct-convolution kernels for these shapes (60-80 ms per conv, see
+            # profiles/r1_v0_vmap_engine_kernel_stats.csv); with it the NHWC bf16 implicit-GEMM
+            # MFMA kernels are selected.  Shapes are static, so the search cost is paid once.
+            torch.backends.cudnn.benchmark = True
 
         # ---- parameter layout (named_parameters order == reference flattening)
         self.names = [n for n, _ in task.model.named_parameters()]

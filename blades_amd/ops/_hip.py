@@ -55,6 +55,13 @@ _gram = _sig("blades_gram", [_P, c_long, c_int, c_long, _P, _P, _P])
 _augment = _sig("blades_augment_batch", [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P], c_int)
 
 
+_pcbn_nchunk = _sig("blades_pcbn_nchunk", [c_int, c_int], c_int)
+_pcbn_fwd = _sig("blades_pcbn_forward", [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, _P],
+                 c_int)
+_pcbn_bwd = _sig("blades_pcbn_backward", [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_long, c_long, c_long,
+                                          c_int, _P, _P, _P, _P, _P, _P, _P], c_int)
+
+
 def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -270,3 +277,75 @@ def augment_batch(x, params, size, mean, std):
     if rc != 0:
         raise ValueError("augment_batch supports up to 4 channels")
     return out
+
+
+# ---------------------------------------------------------------------------
+def _chk_nhwc_bf16(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4
+            and t.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError(f"{name}: expected a CUDA bf16 channels-last 4-D tensor, got {t.dtype} {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+
+
+def pcbn_supported(x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0 and x.shape[1] <= 2048
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool):
+    _chk_nhwc_bf16(x, "x")
+    N, C, H, W = x.shape
+    if N % Kc != 0:
+        raise ValueError("batch is not a multiple of the number of clients")
+    P = (N // Kc) * H * W
+    if res is not None:
+        _chk_nhwc_bf16(res, "res")
+        if res.shape != x.shape:
+            raise ValueError("residual shape mismatch")
+    dev = x.device
+    gamma = _vec(gamma, C, dev, name="gamma")
+    beta = _vec(beta, C, dev, name="beta")
+    nch = _pcbn_nchunk(P, C)
+    partial = torch.empty(Kc * nch * C * 2, device=dev)
+    stats = torch.empty(4, Kc, C, device=dev)
+    y = torch.empty_like(x)
+    rc = _pcbn_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), Kc, P, C, eps, int(relu), _ptr(partial),
+                   _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(y), _stream())
+    if rc != 0:
+        raise ValueError("pcbn_forward: unsupported shape")
+    return y, stats[0], stats[1]
+
+
+def pcbn_backward(x, gy, y, gamma, mean, invstd, Kc: int, coef, U_block, off_gamma: int, off_beta: int,
+                  accumulate: bool, want_gres: bool):
+    _chk_nhwc_bf16(x, "x")
+    _chk_nhwc_bf16(gy, "gy")
+    if gy.shape != x.shape:
+        raise ValueError("gy shape mismatch")
+    if y is not None:
+        _chk_nhwc_bf16(y, "y")
+        if y.shape != x.shape:
+            raise ValueError("y shape mismatch")
+    N, C, H, W = x.shape
+    P = (N // Kc) * H * W
+    dev = x.device
+    gamma = _vec(gamma, C, dev, name="gamma")
+    ld = 0
+    if U_block is not None:
+        K, Dl, ld = _chk_matrix(U_block)
+        if K != Kc or off_gamma + C > Dl or off_beta + C > Dl or off_gamma < 0 or off_beta < 0:
+            raise ValueError("pcbn_backward: update-matrix block does not match")
+        coef = _vec(coef, Kc, dev, name="coef")
+    if mean.numel() != Kc * C or invstd.numel() != Kc * C:
+        raise ValueError("pcbn_backward: stats shape mismatch")
+    nch = _pcbn_nchunk(P, C)
+    partial = torch.empty(Kc * nch * C * 2, device=dev)
+    k = torch.empty(3, Kc, C, device=dev)
+    dx = torch.empty_like(x)
+    gres = torch.empty_like(x) if want_gres else None
+    rc = _pcbn_bwd(_ptr(x), _ptr(gy), _ptr(y), _ptr(gamma), _ptr(mean), _ptr(invstd), Kc, P, C, _ptr(coef),
+                   _ptr(U_block), ld, off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(k[0]), _ptr(k[1]),
+                   _ptr(k[2]), _ptr(dx), _ptr(gres), _stream())
+    if rc != 0:
+        raise ValueError("pcbn_backward: unsupported shape")
+    return dx, gres

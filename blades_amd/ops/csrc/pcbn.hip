@@ -1,0 +1,250 @@
+// Per-client batch normalisation (batch statistics only) for channels-last bf16 activations.
+//
+// x is [Kc][P][C] (client-major NHWC: P = B*H*W pixels of one client's batch, C channels
+// contiguous); statistics are per (client, channel) — the group structure the reference gets
+// implicitly by training one client at a time with BatchNorm2d(track_running_stats=False)
+// (fllib/models/cifar10/resnet_cifar.py:14-30).  fp32 math, bf16 I/O.
+//
+// Forward:  stats (partials -> finalize: scale = gamma*invstd, shift = beta - mean*scale)
+//           apply: y = scale*x + shift (+ residual) (ReLU)            — fused epilogue
+// Backward: reduce: dbeta = sum g, dgamma = sum g*xhat with g = gy * [y > 0]
+//           finalize: writes coef*dgamma / coef*dbeta straight into the update-matrix rows
+//           apply: dx = scale*(g - dbeta/m - xhat*dgamma/m) (+ g as the residual-branch grad)
+//
+// Every pass is a pure stream (16 B per lane, all lanes of a pixel row contiguous) => HBM-bound.
+// Reductions are two-stage with fixed order (no float atomics): bitwise reproducible.
+#include "common.h"
+#include <hip/hip_bf16.h>
+
+namespace {
+
+constexpr int TPB = 256;
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __hip_bfloat16 h = __float2bfloat16(f);
+  return *reinterpret_cast<unsigned short*>(&h);
+}
+
+// partial[(c * nchunk + chunk) * C * 2 + ch * 2 + {0,1}]
+// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g * xhat), g = gy * mask(y>0 if y)
+template <int MODE>
+__global__ __launch_bounds__(TPB) void pcbn_reduce_kernel(const unsigned short* __restrict__ x,
+                                                          const unsigned short* __restrict__ gy,
+                                                          const unsigned short* __restrict__ y,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, int P, int C,
+                                                          int pix_per_chunk, int nchunk,
+                                                          float* __restrict__ partial) {
+  extern __shared__ float red[];  // [TPB][16]
+  const int client = blockIdx.y, chunk = blockIdx.x;
+  const int lpp = C >> 3;  // lanes per pixel
+  const int cg = threadIdx.x % lpp, prow = threadIdx.x / lpp, rows = TPB / lpp;
+  const int p0 = chunk * pix_per_chunk;
+  int p1 = p0 + pix_per_chunk;
+  if (p1 > P) p1 = P;
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = 0.f; b[j] = 0.f; }
+  float mu[8], is[8];
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mu[j] = mean[client * C + cg * 8 + j]; is[j] = invstd[client * C + cg * 8 + j]; }
+  }
+  const size_t base = (size_t)client * P * C + (size_t)cg * 8;
+  for (int p = p0 + prow; p < p1; p += rows) {
+    const size_t off = base + (size_t)p * C;
+    const u16x8 xv = *reinterpret_cast<const u16x8*>(x + off);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float v = bf2f(xv[j]); a[j] += v; b[j] += v * v; }
+    } else {
+      const u16x8 gv = *reinterpret_cast<const u16x8*>(gy + off);
+      u16x8 yv = gv;
+      if (y != nullptr) yv = *reinterpret_cast<const u16x8*>(y + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float g = bf2f(gv[j]);
+        if (y != nullptr && !(bf2f(yv[j]) > 0.f)) g = 0.f;
+        a[j] += g;
+        b[j] += g * (bf2f(xv[j]) - mu[j]) * is[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = a[j]; red[threadIdx.x * 16 + 8 + j] = b[j]; }
+  __syncthreads();
+  // threads [0, lpp*16): one (channel-group, slot) each, fixed-order sum over the pixel rows
+  for (int t = threadIdx.x; t < lpp * 16; t += TPB) {
+    const int g = t / 16, s = t % 16;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += red[(r * lpp + g) * 16 + s];
+    const int ch = g * 8 + (s & 7), which = s >> 3;
+    partial[((size_t)(client * nchunk + chunk) * C + ch) * 2 + which] = acc;
+  }
+}
+
+// forward finalize: one thread per (client, channel)
+__global__ __launch_bounds__(TPB) void pcbn_fwd_finalize_kernel(const float* __restrict__ partial, int Kc, int C, int nchunk,
+                                                                int P, float eps, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ mean,
+                                                                float* __restrict__ invstd, float* __restrict__ scale,
+                                                                float* __restrict__ shift) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= Kc * C) return;
+  const int c = i / C, ch = i % C;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    const float* q = partial + ((size_t)(c * nchunk + k) * C + ch) * 2;
+    s += (double)q[0]; ss += (double)q[1];
+  }
+  const double m = s / P;
+  double var = ss / P - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+  mean[i] = (float)m; invstd[i] = is;
+  scale[i] = g * is; shift[i] = b - (float)m * g * is;
+}
+
+__global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const unsigned short* __restrict__ x,
+                                                             const unsigned short* __restrict__ res,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int P, int C, int relu,
+                                                             unsigned short* __restrict__ y) {
+  const int client = blockIdx.y;
+  const int lpp = C >> 3;
+  const size_t nvec = (size_t)P * lpp;
+  const size_t base = (size_t)client * P * C;
+  for (size_t v = (size_t)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (size_t)gridDim.x * TPB) {
+    const int cg = (int)(v % lpp);
+    const size_t off = base + v * 8;
+    const u16x8 xv = *reinterpret_cast<const u16x8*>(x + off);
+    u16x8 rv = xv;
+    if (res != nullptr) rv = *reinterpret_cast<const u16x8*>(res + off);
+    u16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = client * C + cg * 8 + j;
+      float val = bf2f(xv[j]) * scale[ch] + shift[ch];
+      if (res != nullptr) val += bf2f(rv[j]);
+      if (relu) val = fmaxf(val, 0.f);
+      out[j] = f2bf(val);
+    }
+    *reinterpret_cast<u16x8*>(y + off) = out;
+  }
+}
+
+// backward finalize: dgamma/dbeta -> update-matrix rows (scaled), coefficient tables for apply
+__global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_kernel(const float* __restrict__ partial, int Kc, int C, int nchunk,
+                                                                int P, const float* __restrict__ gamma,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ coef,  // [Kc] sink scale
+                                                                float* __restrict__ U, long ld, long off_gamma,
+                                                                long off_beta, int accumulate,
+                                                                float* __restrict__ k_scale,  // gamma*invstd
+                                                                float* __restrict__ k_b,      // dbeta/m
+                                                                float* __restrict__ k_c) {    // dgamma/m
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= Kc * C) return;
+  const int c = i / C, ch = i % C;
+  double sg = 0.0, sgx = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    const float* q = partial + ((size_t)(c * nchunk + k) * C + ch) * 2;
+    sg += (double)q[0]; sgx += (double)q[1];
+  }
+  const float g = gamma ? gamma[ch] : 1.f;
+  if (U != nullptr) {
+    float* row = U + (size_t)c * ld;
+    const float s = coef[c];
+    if (accumulate) { row[off_gamma + ch] += s * (float)sgx; row[off_beta + ch] += s * (float)sg; }
+    else { row[off_gamma + ch] = s * (float)sgx; row[off_beta + ch] = s * (float)sg; }
+  }
+  k_scale[i] = g * invstd[i];
+  k_b[i] = (float)(sg / P);
+  k_c[i] = (float)(sgx / P);
+}
+
+__global__ __launch_bounds__(TPB) void pcbn_bwd_apply_kernel(const unsigned short* __restrict__ x,
+                                                             const unsigned short* __restrict__ gy,
+                                                             const unsigned short* __restrict__ y,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ k_scale,
+                                                             const float* __restrict__ k_b,
+                                                             const float* __restrict__ k_c, int P, int C,
+                                                             unsigned short* __restrict__ dx,
+                                                             unsigned short* __restrict__ gres) {
+  const int client = blockIdx.y;
+  const int lpp = C >> 3;
+  const size_t nvec = (size_t)P * lpp;
+  const size_t base = (size_t)client * P * C;
+  for (size_t v = (size_t)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (size_t)gridDim.x * TPB) {
+    const int cg = (int)(v % lpp);
+    const size_t off = base + v * 8;
+    const u16x8 xv = *reinterpret_cast<const u16x8*>(x + off);
+    const u16x8 gv = *reinterpret_cast<const u16x8*>(gy + off);
+    u16x8 yv = gv;
+    if (y != nullptr) yv = *reinterpret_cast<const u16x8*>(y + off);
+    u16x8 o, r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = client * C + cg * 8 + j;
+      float g = bf2f(gv[j]);
+      if (y != nullptr && !(bf2f(yv[j]) > 0.f)) g = 0.f;
+      const float xhat = (bf2f(xv[j]) - mean[ch]) * invstd[ch];
+      o[j] = f2bf(k_scale[ch] * (g - k_b[ch] - xhat * k_c[ch]));
+      r[j] = f2bf(g);
+    }
+    *reinterpret_cast<u16x8*>(dx + off) = o;
+    if (gres != nullptr) *reinterpret_cast<u16x8*>(gres + off) = r;
+  }
+}
+
+inline int chunk_pixels(int C) {
+  int p = 262144 / (C * 2);
+  if (p < 64) p = 64;
+  return p;
+}
+
+}  // namespace
+
+BLADES_API int blades_pcbn_nchunk(int P, int C) { return cdiv(P, chunk_pixels(C)); }
+
+// workspace `partial`: Kc * nchunk * C * 2 floats.
+BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* gamma, const float* beta, int Kc,
+                                   int P, int C, float eps, int relu, float* partial, float* mean, float* invstd,
+                                   float* scale, float* shift, void* y, hipStream_t st) {
+  if (C % 8 != 0 || C > 2048 || Kc <= 0 || P <= 0) return 1;
+  const int ppc = chunk_pixels(C), nch = cdiv(P, ppc);
+  hipLaunchKernelGGL((pcbn_reduce_kernel<0>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st,
+                     (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, P, C, ppc, nch, partial);
+  hipLaunchKernelGGL(pcbn_fwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
+                     eps, gamma, beta, mean, invstd, scale, shift);
+  int gx = cdiv((long)P * (C / 8), TPB);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(pcbn_fwd_apply_kernel, dim3(gx, Kc), dim3(TPB), 0, st, (const unsigned short*)x,
+                     (const unsigned short*)res, scale, shift, P, C, relu, (unsigned short*)y);
+  return 0;
+}
+
+// workspace: partial (as forward), k_scale/k_b/k_c: Kc*C floats each.
+BLADES_API int blades_pcbn_backward(const void* x, const void* gy, const void* y, const float* gamma,
+                                    const float* mean, const float* invstd, int Kc, int P, int C, const float* coef,
+                                    float* U, long ld, long off_gamma, long off_beta, int accumulate, float* partial,
+                                    float* k_scale, float* k_b, float* k_c, void* dx, void* gres, hipStream_t st) {
+  if (C % 8 != 0 || C > 2048 || Kc <= 0 || P <= 0) return 1;
+  const int ppc = chunk_pixels(C), nch = cdiv(P, ppc);
+  hipLaunchKernelGGL((pcbn_reduce_kernel<1>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st,
+                     (const unsigned short*)x, (const unsigned short*)gy, (const unsigned short*)y, mean, invstd, P, C,
+                     ppc, nch, partial);
+  hipLaunchKernelGGL(pcbn_bwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
+                     gamma, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c);
+  int gx = cdiv((long)P * (C / 8), TPB);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(pcbn_bwd_apply_kernel, dim3(gx, Kc), dim3(TPB), 0, st, (const unsigned short*)x,
+                     (const unsigned short*)gy, (const unsigned short*)y, mean, invstd, k_scale, k_b, k_c, P, C,
+                     (unsigned short*)dx, (unsigned short*)gres);
+  return 0;
+}

@@ -196,3 +196,60 @@ def test_augment_matches_reference(dev):
     r = aug.apply_reference(x, p)
     o = aug.apply(x.to(dev), p)
     torch.testing.assert_close(o.cpu(), r, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("Kc,B,C,H,relu,res", [(3, 4, 64, 8, True, False), (2, 8, 128, 4, True, True),
+                                               (5, 2, 512, 4, False, False), (2, 16, 64, 32, True, True),
+                                               (1, 64, 256, 8, False, True)])
+def test_pcbn_kernels(dev, Kc, B, C, H, relu, res):
+    from blades_amd.engine import fused
+    from blades_amd import ops
+
+    h = ops._h()
+    g = torch.Generator().manual_seed(1)
+    mk = lambda: (torch.randn(Kc * B, C, H, H, generator=g) * 1.5 + 0.3).to(dev).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    x, r, gy = mk(), (mk() if res else None), mk()
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = torch.randn(C, generator=g).to(dev)
+    y, mean, invstd = h.pcbn_forward(x, r, gamma, beta, Kc, 1e-5, relu)
+    y2, mean2, invstd2 = fused._bn_forward_ref(x, r, gamma, beta, Kc, 1e-5, relu)
+    torch.testing.assert_close(mean, mean2, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(invstd, invstd2, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(y.float(), y2.float(), rtol=2e-2, atol=2e-2)
+    D = 3 * C + 7
+    U = torch.zeros(Kc, D, device=dev)
+    coef = torch.tensor([(-1.0) ** i * (i + 1) for i in range(Kc)], device=dev)
+    dx, gres = h.pcbn_backward(x, gy, y2 if relu else None, gamma, mean2, invstd2, Kc, coef, U, 5, C + 6, False,
+                               res and relu)
+    dx2, gres2, dgamma, dbeta = fused._bn_backward_ref(x, gy, y2, gamma, mean2, invstd2, Kc, relu, res and relu)
+    torch.testing.assert_close(dx.float(), dx2.float(), rtol=3e-2, atol=3e-2)
+    scale = max(1.0, float(dgamma.abs().max()))
+    torch.testing.assert_close(U[:, 5: 5 + C], dgamma * coef[:, None], rtol=1e-3, atol=1e-3 * scale)
+    torch.testing.assert_close(U[:, C + 6: 2 * C + 6], dbeta * coef[:, None], rtol=1e-3, atol=1e-3 * scale)
+    if res and relu:
+        torch.testing.assert_close(gres.float(), gres2.float(), rtol=1e-2, atol=1e-2)
+    assert float(U[:, :5].abs().sum()) == 0 and float(U[:, 2 * C + 6:].abs().sum()) == 0
+
+
+def test_fused_engine_gpu_matches_fp32_reference(dev, tmp_path):
+    """bf16 fused executor on the GPU vs the fp32 vectorised path on the CPU."""
+    from tests.test_engine_paths import build, one_round_updates
+
+    a = build(str(tmp_path), "resnet", "fused")
+    b = build(str(tmp_path), "resnet", "fused")
+    # move a to the GPU with bf16 compute
+    import copy
+    from blades_amd.algorithms.fedavg import FedavgConfig
+
+    cfg = copy.deepcopy(a.config)
+    cfg._is_frozen = False
+    cfg.device, cfg.amp_dtype = "cuda", "bf16"
+    g = cfg.build()
+    g.server.theta.copy_(b.server.theta.to(dev))
+    Ug, _ = one_round_updates(g)
+    Ub, _ = one_round_updates(b)
+    cos = torch.nn.functional.cosine_similarity(Ug.cpu(), Ub, dim=1)
+    assert float(cos.min()) > 0.98, cos
+    rel = (Ug.cpu() - Ub).norm(dim=1) / Ub.norm(dim=1)
+    assert float(rel.max()) < 0.2, rel
