@@ -79,9 +79,8 @@ class _PCConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.ops.aten.convolution_backward(
                 gy, x, w, None, mod.stride, mod.padding, mod.dilation, False, [0, 0], 1, [True, False, False])[0]
-        dw = mod.wgrad(x, gy, Kc, B)  # [Kc, Cout, Cin, kh, kw] fp32 (or None if written in place)
-        if dw is not None:
-            sink.write(mod.weight, dw)
+        if not mod.wgrad_hip(x, gy, Kc):
+            sink.write(mod.weight, mod.wgrad(x, gy, Kc, B))  # [Kc, Cout, Cin, kh, kw]
         if mod.bias is not None:
             sink.write(mod.bias, gy.float().reshape(Kc, B, gy.shape[1], -1).sum(dim=(1, 3)))
         return dx, None, None
@@ -97,6 +96,24 @@ class PCConv2d(nn.Module):
 
     def forward(self, x):
         return _PCConvFn.apply(x, self.weight, self)
+
+    def wgrad_hip(self, x, gy, Kc) -> bool:
+        """MFMA kernel path: dW_c lands, scaled, in the update-matrix rows.  False = not applicable."""
+        if not x.is_cuda:
+            return False
+        h = _hipmod()
+        ks = self.weight.shape[2:]
+        if not h.conv_wgrad_supported(x, gy, ks, self.stride, self.padding, self.dilation):
+            return False
+        x = x.contiguous(memory_format=torch.channels_last)
+        sink = self.sink
+        off, _ = sink.offsets[id(self.weight)]
+        acc = id(self.weight) in sink._written
+        ok = h.conv_wgrad_(x, gy, Kc, sink.block, off, sink.scale, acc, int(ks[0]), int(self.stride[0]),
+                           int(self.padding[0]))
+        if ok:
+            sink._written.add(id(self.weight))
+        return ok
 
     def wgrad(self, x, gy, Kc, B):
         """Per-client weight gradient.  Reference implementation: regroup to

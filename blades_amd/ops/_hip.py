@@ -289,6 +289,7 @@ def _chk_nhwc_bf16(t: torch.Tensor, name: str):
 
 def pcbn_supported(x: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0 and x.shape[1] <= 2048
+            and 256 % (x.shape[1] // 8) == 0
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
@@ -349,3 +350,112 @@ def pcbn_backward(x, gy, y, gamma, mean, invstd, Kc: int, coef, U_block, off_gam
     if rc != 0:
         raise ValueError("pcbn_backward: unsupported shape")
     return dx, gres
+
+
+# ---------------------------------------------------------------------------
+# per-client conv weight gradient
+_conv_wgrad = _sig("blades_conv_wgrad", [_P, _P, _P, c_long, c_long, _P, c_int] + [c_int] * 11 + [_P] + [c_int] * 4
+                   + [_P], c_int)
+_wgrad_plans = {}
+
+
+def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
+    """Per-step staging table of the wgrad kernel (see ops/csrc/conv_wgrad.hip)."""
+    import numpy as np
+
+    key = (B, H, W, Ho, Wo, ks, stride, pad, str(device))
+    if key in _wgrad_plans:
+        return _wgrad_plans[key]
+    qpr = -(-Wo // 4)
+    Q = B * Ho * qpr
+    S = -(-Q // 8)
+    q = np.arange(S * 8)
+    valid = q < Q
+    qq = np.minimum(q, Q - 1)
+    b = qq // (Ho * qpr)
+    oh = (qq // qpr) % Ho
+    ow0 = (qq % qpr) * 4
+    ih0 = oh * stride - pad
+    gi0 = b * H + ih0
+    gy_base = np.where(valid, (b * Ho + oh) * Wo + ow0, -1)
+    lo_row = b * H + np.clip(ih0, 0, H - 1)
+    hi_row = b * H + np.clip(ih0 + ks - 1, 0, H - 1)
+    big = np.iinfo(np.int64).max
+    glo = np.where(valid, lo_row, big).reshape(S, 8).min(axis=1)
+    ghi = np.where(valid, hi_row, -1).reshape(S, 8).max(axis=1)
+    table = np.zeros((S, 34), dtype=np.int32)
+    prev = -1
+    window = 1
+    max_new = 0
+    for s in range(S):
+        lo = max(prev + 1, int(glo[s]))
+        hi = int(ghi[s])
+        table[s, 0], table[s, 1] = lo, hi
+        max_new = max(max_new, (hi - lo + 1) * W)
+        prev = max(prev, hi)
+        nxt = int(ghi[s + 1]) if s + 1 < S else hi
+        window = max(window, nxt - int(glo[s]) + 1)
+    table[:, 2::4] = gy_base.reshape(S, 8)
+    table[:, 3::4] = gi0.reshape(S, 8)
+    table[:, 4::4] = ih0.reshape(S, 8)
+    table[:, 5::4] = ow0.reshape(S, 8)
+    nlines = 1
+    while nlines < window:
+        nlines *= 2
+    # slots per line: padded width (+3 so the last quad of a ragged row stays inside the line),
+    # made = 4 (mod 8) so lines sit 128 B (mod 256 B) apart -> adjacent-row quads do not bank-conflict
+    need = W + 2 * pad + 3
+    if stride == 2:
+        need = 2 * (-(-(W + 2 * pad) // 2) + 2)
+    wslots = need
+    while wslots % 8 != 4:
+        wslots += 1
+    passes = -(-max_new // 32)
+    plan = dict(table=torch.from_numpy(table).to(device), nsteps=S, nlines=nlines, wslots=wslots, passes=passes)
+    _wgrad_plans[key] = plan
+    return plan
+
+
+def conv_wgrad_supported(x, gy, ks, stride, pad, dilation) -> bool:
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and gy.dtype == torch.bfloat16 and x.dim() == 4):
+        return False
+    Cin, Cout = x.shape[1], gy.shape[1]
+    if Cin % 16 or Cout % 16 or ks[0] != ks[1] or ks[0] not in (1, 3) or stride[0] != stride[1] \
+            or stride[0] not in (1, 2) or pad[0] != pad[1] or tuple(dilation) != (1, 1):
+        return False
+    if stride[0] == 2 and (x.shape[3] + 2 * pad[0]) % 2:
+        return False
+    return True
+
+
+def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: int, stride: int, pad: int):
+    """Writes coef[c] * dW_c into U_block[c, off : off + Cout*Cin*ks*ks] for every client c."""
+    _chk_nhwc_bf16(x, "x")
+    _chk_nhwc_bf16(gy, "gy")
+    N, Cin, H, W = x.shape
+    N2, Cout, Ho, Wo = gy.shape
+    if N != N2 or N % Kc:
+        raise ValueError("conv_wgrad_: batch mismatch")
+    B = N // Kc
+    if Ho != (H + 2 * pad - ks) // stride + 1 or Wo != (W + 2 * pad - ks) // stride + 1:
+        raise ValueError("conv_wgrad_: output size does not match the convolution geometry")
+    K, Dl, ld = _chk_matrix(U_block)
+    numel = Cout * Cin * ks * ks
+    if K != Kc or off < 0 or off + numel > Dl:
+        raise ValueError("conv_wgrad_: update-matrix block does not match")
+    coef = _vec(coef, Kc, x.device, name="coef")
+    plan = _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, x.device)
+    if plan["passes"] > 4:
+        return False
+    tmt = 4
+    n_ci_tiles = -(-Cin // 64)
+    while tmt > 1 and (Cout % (tmt * 16) or Kc * (Cout // (tmt * 16)) * n_ci_tiles < 256):
+        tmt //= 2
+    rc = _conv_wgrad(_ptr(x), _ptr(gy), _ptr(U_block), ld, off, _ptr(coef), int(accumulate), Kc, B, H, W, Cin, Ho,
+                     Wo, Cout, ks, stride, pad, _ptr(plan["table"]), plan["nsteps"], plan["nlines"], plan["wslots"],
+                     tmt, _stream())
+    if rc == 3:  # staging does not fit in LDS
+        return False
+    if rc != 0:
+        raise ValueError(f"conv_wgrad_: unsupported configuration (rc={rc})")
+    return True

@@ -117,8 +117,13 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const unsigned shor
   const int lpp = C >> 3;
   const size_t nvec = (size_t)P * lpp;
   const size_t base = (size_t)client * P * C;
+  // TPB and the grid stride are multiples of lpp, so a thread keeps its channel group:
+  // the per-(client, channel) tables live in registers for the whole sweep.
+  const int cg = threadIdx.x % lpp;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[client * C + cg * 8 + j]; sh[j] = shift[client * C + cg * 8 + j]; }
   for (size_t v = (size_t)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (size_t)gridDim.x * TPB) {
-    const int cg = (int)(v % lpp);
     const size_t off = base + v * 8;
     const u16x8 xv = *reinterpret_cast<const u16x8*>(x + off);
     u16x8 rv = xv;
@@ -126,8 +131,7 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const unsigned shor
     u16x8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int ch = client * C + cg * 8 + j;
-      float val = bf2f(xv[j]) * scale[ch] + shift[ch];
+      float val = bf2f(xv[j]) * sc[j] + sh[j];
       if (res != nullptr) val += bf2f(rv[j]);
       if (relu) val = fmaxf(val, 0.f);
       out[j] = f2bf(val);
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const unsigned shor
 // backward finalize: dgamma/dbeta -> update-matrix rows (scaled), coefficient tables for apply
 __global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_kernel(const float* __restrict__ partial, int Kc, int C, int nchunk,
                                                                 int P, const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ coef,  // [Kc] sink scale
                                                                 float* __restrict__ U, long ld, long off_gamma,
@@ -161,27 +166,33 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_kernel(const float* __r
     if (accumulate) { row[off_gamma + ch] += s * (float)sgx; row[off_beta + ch] += s * (float)sg; }
     else { row[off_gamma + ch] = s * (float)sgx; row[off_beta + ch] = s * (float)sg; }
   }
-  k_scale[i] = g * invstd[i];
-  k_b[i] = (float)(sg / P);
-  k_c[i] = (float)(sgx / P);
+  // dx = ks*(g - db/m - xhat*dg/m) = A*g + Bx*x + Cc with xhat = (x - mean)*invstd
+  const float ks = g * invstd[i], kb = (float)(sg / P), kc = (float)(sgx / P);
+  k_scale[i] = ks;                              // A
+  k_b[i] = -ks * invstd[i] * kc;                // Bx
+  k_c[i] = ks * (mean[i] * invstd[i] * kc - kb);  // Cc
 }
 
 __global__ __launch_bounds__(TPB) void pcbn_bwd_apply_kernel(const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ gy,
                                                              const unsigned short* __restrict__ y,
-                                                             const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd,
-                                                             const float* __restrict__ k_scale,
-                                                             const float* __restrict__ k_b,
-                                                             const float* __restrict__ k_c, int P, int C,
+                                                             const float* __restrict__ k_a,
+                                                             const float* __restrict__ k_bx,
+                                                             const float* __restrict__ k_cc, int P, int C,
                                                              unsigned short* __restrict__ dx,
                                                              unsigned short* __restrict__ gres) {
   const int client = blockIdx.y;
   const int lpp = C >> 3;
   const size_t nvec = (size_t)P * lpp;
   const size_t base = (size_t)client * P * C;
+  const int cg = threadIdx.x % lpp;  // loop-invariant, see pcbn_fwd_apply_kernel
+  float ka[8], kb[8], kc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = client * C + cg * 8 + j;
+    ka[j] = k_a[ch]; kb[j] = k_bx[ch]; kc[j] = k_cc[ch];
+  }
   for (size_t v = (size_t)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (size_t)gridDim.x * TPB) {
-    const int cg = (int)(v % lpp);
     const size_t off = base + v * 8;
     const u16x8 xv = *reinterpret_cast<const u16x8*>(x + off);
     const u16x8 gv = *reinterpret_cast<const u16x8*>(gy + off);
@@ -190,11 +201,9 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_apply_kernel(const unsigned shor
     u16x8 o, r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int ch = client * C + cg * 8 + j;
       float g = bf2f(gv[j]);
       if (y != nullptr && !(bf2f(yv[j]) > 0.f)) g = 0.f;
-      const float xhat = (bf2f(xv[j]) - mean[ch]) * invstd[ch];
-      o[j] = f2bf(k_scale[ch] * (g - k_b[ch] - xhat * k_c[ch]));
+      o[j] = f2bf(ka[j] * g + kb[j] * bf2f(xv[j]) + kc[j]);
       r[j] = f2bf(g);
     }
     *reinterpret_cast<u16x8*>(dx + off) = o;
@@ -216,7 +225,7 @@ BLADES_API int blades_pcbn_nchunk(int P, int C) { return cdiv(P, chunk_pixels(C)
 BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* gamma, const float* beta, int Kc,
                                    int P, int C, float eps, int relu, float* partial, float* mean, float* invstd,
                                    float* scale, float* shift, void* y, hipStream_t st) {
-  if (C % 8 != 0 || C > 2048 || Kc <= 0 || P <= 0) return 1;
+  if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
   const int ppc = chunk_pixels(C), nch = cdiv(P, ppc);
   hipLaunchKernelGGL((pcbn_reduce_kernel<0>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st,
                      (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, P, C, ppc, nch, partial);
@@ -234,17 +243,17 @@ BLADES_API int blades_pcbn_backward(const void* x, const void* gy, const void* y
                                     const float* mean, const float* invstd, int Kc, int P, int C, const float* coef,
                                     float* U, long ld, long off_gamma, long off_beta, int accumulate, float* partial,
                                     float* k_scale, float* k_b, float* k_c, void* dx, void* gres, hipStream_t st) {
-  if (C % 8 != 0 || C > 2048 || Kc <= 0 || P <= 0) return 1;
+  if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
   const int ppc = chunk_pixels(C), nch = cdiv(P, ppc);
   hipLaunchKernelGGL((pcbn_reduce_kernel<1>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st,
                      (const unsigned short*)x, (const unsigned short*)gy, (const unsigned short*)y, mean, invstd, P, C,
                      ppc, nch, partial);
   hipLaunchKernelGGL(pcbn_bwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
-                     gamma, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c);
+                     gamma, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c);
   int gx = cdiv((long)P * (C / 8), TPB);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL(pcbn_bwd_apply_kernel, dim3(gx, Kc), dim3(TPB), 0, st, (const unsigned short*)x,
-                     (const unsigned short*)gy, (const unsigned short*)y, mean, invstd, k_scale, k_b, k_c, P, C,
+                     (const unsigned short*)gy, (const unsigned short*)y, k_scale, k_b, k_c, P, C,
                      (unsigned short*)dx, (unsigned short*)gres);
   return 0;
 }

@@ -253,3 +253,47 @@ def test_fused_engine_gpu_matches_fp32_reference(dev, tmp_path):
     assert float(cos.min()) > 0.98, cos
     rel = (Ug.cpu() - Ub).norm(dim=1) / Ub.norm(dim=1)
     assert float(rel.max()) < 0.2, rel
+
+
+@pytest.mark.parametrize("Kc,B,Cin,Cout,H,ks,stride,pad", [
+    (3, 4, 64, 64, 32, 3, 1, 1),
+    (2, 8, 64, 128, 32, 3, 2, 1),
+    (2, 4, 128, 128, 16, 3, 1, 1),
+    (3, 4, 128, 256, 16, 3, 2, 1),
+    (2, 4, 256, 256, 8, 3, 1, 1),
+    (2, 3, 512, 512, 4, 3, 1, 1),
+    (2, 4, 64, 128, 32, 1, 2, 0),
+    (2, 4, 256, 512, 8, 1, 2, 0),
+    (2, 2, 32, 64, 13, 3, 1, 0),
+    (1, 5, 16, 48, 11, 3, 1, 1),
+])
+def test_conv_wgrad_kernel(dev, Kc, B, Cin, Cout, H, ks, stride, pad):
+    import torch.nn.functional as F
+    from blades_amd import ops
+
+    h = ops._h()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(Kc * B, Cin, H, H, generator=g).to(dev).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    Ho = (H + 2 * pad - ks) // stride + 1
+    gy = torch.randn(Kc * B, Cout, Ho, Ho, generator=g).to(dev).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    n = Cout * Cin * ks * ks
+    U = torch.full((Kc, n + 11), 7.0, device=dev)
+    coef = torch.tensor([(-0.5) ** i for i in range(Kc)], device=dev)
+    assert h.conv_wgrad_supported(x, gy, (ks, ks), (stride, stride), (pad, pad), (1, 1))
+    assert h.conv_wgrad_(x, gy, Kc, U, 5, coef, False, ks, stride, pad)
+    # fp32 reference on the bf16-rounded inputs
+    ref = torch.empty(Kc, Cout, Cin, ks, ks, device=dev)
+    w = torch.zeros(Cout, Cin, ks, ks, device=dev)
+    for c in range(Kc):
+        xs, gs = x[c * B:(c + 1) * B].float(), gy[c * B:(c + 1) * B].float()
+        ref[c] = torch.ops.aten.convolution_backward(gs, xs, w, None, [stride] * 2, [pad] * 2, [1, 1], False, [0, 0],
+                                                     1, [False, True, False])[1] * coef[c]
+    got = U[:, 5:5 + n].reshape(Kc, Cout, Cin, ks, ks)
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3 * scale)
+    assert float((U[:, :5] - 7).abs().sum()) == 0 and float((U[:, 5 + n:] - 7).abs().sum()) == 0
+    # accumulate mode
+    assert h.conv_wgrad_(x, gy, Kc, U, 5, coef, True, ks, stride, pad)
+    torch.testing.assert_close(U[:, 5:5 + n].reshape(Kc, Cout, Cin, ks, ks), 2 * ref, rtol=2e-3, atol=4e-3 * scale)

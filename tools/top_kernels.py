@@ -3,7 +3,7 @@ import csv
 import sys
 
 path, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 30
-rows = list(csv.DictReader(open(path)))
+rows = [r for r in csv.DictReader(open(path)) if not r["Name"].startswith("naive_conv")]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total kernel time {tot/1e6:.1f} ms over {len(rows)} kernels")
 for r in rows[:n]:
