@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--aggregator", default="Median")
     ap.add_argument("--adversary", default="ALIEAdversary")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=50, help="clients vectorised per kernel chunk")
+    ap.add_argument("--chunk", type=int, default=100, help="clients vectorised per kernel chunk")
     ap.add_argument("--amp", default="bf16")
     ap.add_argument("--samples-per-client", type=int, default=128)
     ap.add_argument("--cpu", action="store_true", help="debug: run on CPU/gloo")
@@ -80,13 +80,23 @@ def main():
         if rt.device.type == "cuda":
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def note(msg):
+        if rt.is_main:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    note(f"setup done: K={K} f={f} D={algo.engine.D} world={world}")
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         algo.train()
+        sync()
+        note(f"warmup round {i} (includes MIOpen kernel search): {time.perf_counter() - tw:.1f}s")
     sync()
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    for i in range(args.steps):
         last = algo.train()
+        if (i + 1) % 10 == 0:
+            note(f"round {i + 1}/{args.steps}")
     sync()
     elapsed = time.perf_counter() - t0
     if rt.distributed:

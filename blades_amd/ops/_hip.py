@@ -354,8 +354,8 @@ def pcbn_backward(x, gy, y, gamma, mean, invstd, Kc: int, coef, U_block, off_gam
 
 # ---------------------------------------------------------------------------
 # per-client conv weight gradient
-_conv_wgrad = _sig("blades_conv_wgrad", [_P, _P, _P, c_long, c_long, _P, c_int] + [c_int] * 11 + [_P] + [c_int] * 4
-                   + [_P], c_int)
+_conv_wgrad = _sig("blades_conv_wgrad", [_P, _P, _P, c_long, c_long, _P, c_int] + [c_int] * 11 + [_P] + [c_int] * 5
+                   + [_P, c_int, c_int, c_long, _P], c_int)
 _wgrad_plans = {}
 
 
@@ -383,7 +383,7 @@ def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
     big = np.iinfo(np.int64).max
     glo = np.where(valid, lo_row, big).reshape(S, 8).min(axis=1)
     ghi = np.where(valid, hi_row, -1).reshape(S, 8).max(axis=1)
-    table = np.zeros((S, 34), dtype=np.int32)
+    table = np.zeros((S, 36), dtype=np.int32)
     prev = -1
     window = 1
     max_new = 0
@@ -391,14 +391,15 @@ def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
         lo = max(prev + 1, int(glo[s]))
         hi = int(ghi[s])
         table[s, 0], table[s, 1] = lo, hi
+        table[s, 34] = int(glo[s])
         max_new = max(max_new, (hi - lo + 1) * W)
         prev = max(prev, hi)
         nxt = int(ghi[s + 1]) if s + 1 < S else hi
         window = max(window, nxt - int(glo[s]) + 1)
-    table[:, 2::4] = gy_base.reshape(S, 8)
-    table[:, 3::4] = gi0.reshape(S, 8)
-    table[:, 4::4] = ih0.reshape(S, 8)
-    table[:, 5::4] = ow0.reshape(S, 8)
+    table[:, 2:34:4] = gy_base.reshape(S, 8)
+    table[:, 3:34:4] = gi0.reshape(S, 8)
+    table[:, 4:34:4] = ih0.reshape(S, 8)
+    table[:, 5:34:4] = ow0.reshape(S, 8)
     nlines = 1
     while nlines < window:
         nlines *= 2
@@ -414,6 +415,19 @@ def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
     plan = dict(table=torch.from_numpy(table).to(device), nsteps=S, nlines=nlines, wslots=wslots, passes=passes)
     _wgrad_plans[key] = plan
     return plan
+
+
+_scratch_buf = {}
+
+
+def _scratch(n: int, device) -> torch.Tensor:
+    """Grow-only fp32 workspace per device (stream-ordered reuse: all users run on the current stream)."""
+    key = str(device)
+    buf = _scratch_buf.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(int(n * 1.25) + 1024, device=device, dtype=torch.float32)
+        _scratch_buf[key] = buf
+    return buf
 
 
 def conv_wgrad_supported(x, gy, ks, stride, pad, dilation) -> bool:
@@ -444,16 +458,32 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
     if K != Kc or off < 0 or off + numel > Dl:
         raise ValueError("conv_wgrad_: update-matrix block does not match")
     coef = _vec(coef, Kc, x.device, name="coef")
+    x_client_stride = B * H * W * Cin
+    rmul, cmul = W, 1
+    if ks == 1 and pad == 0 and stride > 1:
+        # a strided 1x1 conv only ever touches x[:, ::s, ::s]: run it as a stride-1 1x1 conv on that
+        # virtual sub-image (addressed in place, nothing is copied)
+        rmul, cmul = stride * W, stride
+        H, W, stride = Ho, Wo, 1
     plan = _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, x.device)
     if plan["passes"] > 4:
         return False
     tmt = 4
     n_ci_tiles = -(-Cin // 64)
-    while tmt > 1 and (Cout % (tmt * 16) or Kc * (Cout // (tmt * 16)) * n_ci_tiles < 256):
+    while tmt > 1 and Cout % (tmt * 16):
         tmt //= 2
+    # Too few (client, tile) blocks to fill 256 CUs (the 64-channel layers): split the pixel
+    # reduction over blocks; partial sums go through a scratch slab and are added in fixed order.
+    blocks = Kc * (Cout // (tmt * 16)) * n_ci_tiles
+    split = 1
+    if blocks < 512:
+        split = max(1, min(8, -(-512 // blocks), plan["nsteps"] // 16))
+    scratch = None
+    if split > 1:
+        scratch = _scratch(split * Kc * numel, x.device)
     rc = _conv_wgrad(_ptr(x), _ptr(gy), _ptr(U_block), ld, off, _ptr(coef), int(accumulate), Kc, B, H, W, Cin, Ho,
                      Wo, Cout, ks, stride, pad, _ptr(plan["table"]), plan["nsteps"], plan["nlines"], plan["wslots"],
-                     tmt, _stream())
+                     tmt, split, _ptr(scratch), rmul, cmul, x_client_stride, _stream())
     if rc == 3:  # staging does not fit in LDS
         return False
     if rc != 0:
