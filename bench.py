@@ -95,8 +95,8 @@ def main():
     last = None
     for i in range(args.steps):
         last = algo.train()
-        if (i + 1) % 10 == 0:
-            note(f"round {i + 1}/{args.steps}")
+        if (i + 1) % 10 == 0 or os.environ.get("BENCH_VERBOSE"):
+            note(f"round {i + 1}/{args.steps} train_loss={last.get('train_loss')}")
     sync()
     elapsed = time.perf_counter() - t0
     if rt.distributed:

@@ -151,14 +151,18 @@ class AttackclippedclusteringAdversary(Adversary):
 
     def forge(self, algorithm, U, ctx):
         bm = algorithm.benign_mask > 0
+        # index-based logic below runs in *client* order so that it does not depend on how clients are
+        # laid out over ranks (rows are rank-major)
+        rc = algorithm.row_clients.to(U.device)
         bidx = torch.nonzero(bm).flatten()
+        bidx = bidx[torch.argsort(rc[bidx])]
         mean = ops.col_mean(U, algorithm.benign_mask)
-        G = global_gram(U, ctx)[bm][:, bm]
+        G = global_gram(U, ctx)[bidx][:, bidx]
         dots = ops.row_dot(U, mean)
         mm = (mean * mean).sum().unsqueeze(0)
         if ctx.distributed:
             ctx.all_reduce(dots), ctx.all_reduce(mm)
-        dots = dots[bm].double().cpu().numpy()
+        dots = dots[bidx].double().cpu().numpy()
         mean_norm = float(mm.sqrt())
         norms = G.diagonal().clamp_min(0).sqrt().double().cpu().numpy()
         dis = cosine_distance_from_gram(G)
@@ -176,7 +180,8 @@ class AttackclippedclusteringAdversary(Adversary):
         # mal = alpha * mean + beta * x_far
         alpha, beta = 0.0, 1.0 / max(norms[far], 1e-16)
         x_far = U[bidx[far]].clone()
-        rows = algorithm.malicious_rows.tolist()
+        mrows = algorithm.malicious_rows
+        rows = mrows[torch.argsort(algorithm.malicious_row_clients.to(mrows.device))].tolist()
         for r in rows:
             if theta + theta_cross >= math.pi:
                 alpha, beta = -10.0, 0.0

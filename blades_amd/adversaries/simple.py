@@ -74,7 +74,7 @@ class NoiseAdversary(Adversary):
 
     def forge(self, algorithm, U, ctx):
         rows = algorithm.malicious_rows
-        pairs = torch.stack([rows.cpu(), rows.cpu()], dim=1)
+        pairs = torch.stack([rows.cpu(), algorithm.malicious_row_clients.cpu()], dim=1)
         seed = int(getattr(self.global_config, "seed", 0) or 0)
         ops.add_normal_rows_(U, pairs, seed, 2000 + self._round, ctx.col_offset, ctx.d_total,
                              float(self._noise_mean), float(self._noise_std), True)

@@ -129,6 +129,8 @@ class Fedavg(Algorithm):
         self._malicious_flags = [bool(c.is_malicious) for c in clients]
         self._benign_mask = self.engine.row_mask([not m for m in self._malicious_flags])
         self._malicious_rows = torch.nonzero(self._benign_mask == 0).flatten()
+        self._malicious_row_clients = torch.as_tensor(
+            self.engine.plan.client_of_row[self._malicious_rows.cpu().numpy()], dtype=torch.int64)
         self.update_matrix: Optional[torch.Tensor] = None
 
     def _engine_runtime(self):
@@ -158,6 +160,17 @@ class Fedavg(Algorithm):
     @property
     def malicious_rows(self) -> torch.Tensor:
         return self._malicious_rows
+
+    @property
+    def row_clients(self) -> torch.Tensor:
+        """[K] global client index of every row of the update matrix."""
+        return torch.as_tensor(self.engine.plan.client_of_row, dtype=torch.int64)
+
+    @property
+    def malicious_row_clients(self) -> torch.Tensor:
+        """Global client index of each entry of ``malicious_rows`` (rows are rank-major, so the
+        row number is not the client number when several ranks take part)."""
+        return self._malicious_row_clients
 
     def _build_local_results(self, U: torch.Tensor):
         """Reference-style ``local_results`` view (single rank only): a list of

@@ -52,10 +52,21 @@ class BatchAugment:
         self.erase_ratio = erase_ratio
 
     # ------------------------------------------------------------------
-    def draw(self, n: int, generator: Optional[torch.Generator] = None, height: int = 32, width: int = 32):
-        """Random decisions for ``n`` batches -> float32 CPU tensor [n, N_PARAMS]."""
+    N_UNIFORMS = 9
+
+    def draw(self, n: int, generator: Optional[torch.Generator] = None, height: int = 32, width: int = 32,
+             uniforms: Optional[torch.Tensor] = None):
+        """Random decisions for ``n`` batches -> float32 CPU tensor [n, N_PARAMS].
+
+        ``uniforms`` ([n, N_UNIFORMS] in [0,1)) replaces the generator: the engine passes
+        counter-based draws keyed by (client, round) so augmentation does not depend on how
+        clients are spread over ranks."""
         g = generator
-        u = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+        if uniforms is not None:
+            cols = iter(uniforms.float().cpu().unbind(dim=1))
+            u = lambda *s: next(cols)  # noqa: E731
+        else:
+            u = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
         area = height * width
         frac = self.scale[0] + (self.scale[1] - self.scale[0]) * u(n)
         side = torch.round(torch.sqrt(frac * area)).clamp(1, min(height, width))  # ratio = 1

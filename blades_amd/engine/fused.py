@@ -21,6 +21,7 @@ channels-last, bf16 (or the engine's amp dtype); reductions and the per-client
 gradients are fp32.
 """
 import copy
+import os as _os
 from typing import Dict, Optional
 
 import torch
@@ -99,7 +100,7 @@ class PCConv2d(nn.Module):
 
     def wgrad_hip(self, x, gy, Kc) -> bool:
         """MFMA kernel path: dW_c lands, scaled, in the update-matrix rows.  False = not applicable."""
-        if not x.is_cuda:
+        if not x.is_cuda or _os.environ.get("BLADES_DISABLE_HIP_WGRAD") == "1":
             return False
         h = _hipmod()
         ks = self.weight.shape[2:]

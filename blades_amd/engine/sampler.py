@@ -16,7 +16,8 @@ import torch
 
 
 class DeviceSampler:
-    def __init__(self, lengths: np.ndarray, offsets: np.ndarray, batch_size: int, device, seed: int = 0):
+    def __init__(self, lengths: np.ndarray, offsets: np.ndarray, batch_size: int, device, seed: int = 0,
+                 client_uids: np.ndarray = None):
         self.n = np.asarray(lengths, dtype=np.int64)
         self.offsets_t = torch.as_tensor(np.asarray(offsets, dtype=np.int64), device=device)
         self.n_t = torch.as_tensor(self.n, device=device)
@@ -24,8 +25,12 @@ class DeviceSampler:
         self.device = device
         self.K = len(self.n)
         self.nmax = int(self.n.max()) if self.K else 0
-        self.gen = torch.Generator()  # CPU generator: the same permutations on every device type
-        self.gen.manual_seed(int(seed))
+        # Shuffle keys are a counter-based hash of (seed, client uid, epoch, position): the batches a
+        # client sees do not depend on the device type, the rank it runs on, or the number of ranks.
+        self.seed = int(seed)
+        self.uids = np.arange(self.K, dtype=np.int64) if client_uids is None else np.asarray(client_uids,
+                                                                                             dtype=np.int64)
+        self.epoch = np.zeros(self.K, dtype=np.int64)
         self.cursor = np.zeros(self.K, dtype=np.int64)
         self.perm = torch.zeros(self.K, max(self.nmax, 1), dtype=torch.int64, device=device)
         self._ar = torch.arange(self.B, device=device)
@@ -33,8 +38,16 @@ class DeviceSampler:
             self._reshuffle(np.arange(self.K))
 
     def _reshuffle(self, rows: np.ndarray):
+        from blades_amd.ops.reference import _philox4x32
+
         r = torch.as_tensor(rows, device=self.device)
-        keys = torch.rand(len(rows), self.nmax, generator=self.gen).to(self.device)
+        pos = torch.arange(self.nmax, dtype=torch.int64, device=self.device).unsqueeze(0).expand(len(rows), -1)
+        uid = torch.as_tensor(self.uids[rows], device=self.device).unsqueeze(1).expand_as(pos)
+        ep = torch.as_tensor(self.epoch[rows], device=self.device).unsqueeze(1).expand_as(pos)
+        w = _philox4x32(pos, uid & 0xFFFFFFFF, ep & 0xFFFFFFFF, torch.full_like(pos, 7), self.seed & 0xFFFFFFFF,
+                        (self.seed >> 32) & 0xFFFFFFFF)
+        keys = (w[0] * 4294967296 + w[1]).double() / float(2 ** 64)  # 64-bit keys: ties are negligible
+        self.epoch[rows] += 1
         invalid = torch.arange(self.nmax, device=self.device).unsqueeze(0) >= self.n_t[r].unsqueeze(1)
         keys.masked_fill_(invalid, 2.0)
         self.perm[r] = keys.argsort(dim=1)
@@ -61,9 +74,9 @@ class DeviceSampler:
         return idx
 
     def state_dict(self):
-        return {"cursor": self.cursor.copy(), "perm": self.perm.cpu(), "gen": self.gen.get_state()}
+        return {"cursor": self.cursor.copy(), "perm": self.perm.cpu(), "epoch": self.epoch.copy()}
 
     def load_state_dict(self, s):
         self.cursor = np.asarray(s["cursor"]).copy()
         self.perm.copy_(s["perm"].to(self.device))
-        self.gen.set_state(s["gen"])
+        self.epoch = np.asarray(s["epoch"]).copy()

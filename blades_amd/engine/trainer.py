@@ -104,11 +104,10 @@ class ClientEngine:
         self._train_rows = np.array([r for r, i in enumerate(self.local_ids) if self._trains[r]], dtype=np.int64)
         train_ids = [ids[r] for r in self._train_rows]
         self.train_store = dataset.device_store(train_ids, self.device, "train")
+        self._train_uids = np.array([self.local_ids[r] for r in self._train_rows], dtype=np.int64)
         self.sampler = DeviceSampler(self.train_store.lengths, self.train_store.offsets, self.B, self.device,
-                                     seed=self.seed * 7919 + runtime.rank)
+                                     seed=self.seed * 7919 + 1, client_uids=self._train_uids)
         self.test_store = dataset.device_store(ids, self.device, "test")
-        self.aug_gen = torch.Generator()
-        self.aug_gen.manual_seed(self.seed * 104729 + runtime.rank)
 
         # ---- persistent buffers
         self.U_row = torch.zeros(self.Kloc, self.Dpad, dtype=torch.float32, device=self.device)
@@ -175,12 +174,25 @@ class ClientEngine:
         tf = self.dataset.train_transform
         if tf is not None:
             if hasattr(tf, "draw"):
-                X = tf.apply(X, tf.draw(Kc, self.aug_gen, X.shape[-2], X.shape[-1]))
+                X = tf.apply(X, tf.draw(Kc, None, X.shape[-2], X.shape[-1], uniforms=self._aug_uniforms(srows, tf)))
             else:
                 X = torch.stack([tf(X[c]) for c in range(Kc)])
         if bool((flip > 0).any()):
             Y = torch.where(flip.unsqueeze(1) > 0, flip.unsqueeze(1) - 1 - Y, Y)
         return X, Y
+
+    def _aug_uniforms(self, srows: np.ndarray, tf) -> torch.Tensor:
+        """[Kc, N_UNIFORMS] uniforms keyed by (seed, client uid, augmentation call counter)."""
+        from blades_amd.ops.reference import _philox4x32
+
+        self._aug_calls = getattr(self, "_aug_calls", 0) + 1
+        n = tf.N_UNIFORMS
+        uid = torch.as_tensor(self._train_uids[srows], dtype=torch.int64).unsqueeze(1).expand(-1, n)
+        j = torch.arange(n, dtype=torch.int64).unsqueeze(0).expand(len(srows), -1)
+        call = torch.full_like(j, self._aug_calls & 0xFFFFFFFF)
+        sd = self.seed * 104729 + 3
+        w = _philox4x32(j, uid & 0xFFFFFFFF, call, torch.full_like(j, 11), sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF)
+        return (w[0] >> 8).float() * (1.0 / 16777216.0)
 
     @staticmethod
     def _clip_coef(sqnorm: torch.Tensor, thr: torch.Tensor) -> torch.Tensor:
@@ -418,12 +430,12 @@ class ClientEngine:
 
     # -- checkpoint -------------------------------------------------------
     def state_dict(self):
-        return {"sampler": self.sampler.state_dict(), "aug_gen": self.aug_gen.get_state(),
+        return {"sampler": self.sampler.state_dict(), "aug_calls": getattr(self, "_aug_calls", 0),
                 "M": None if self.M is None else self.M.cpu(), "mom_init": self._mom_init, "round": self.round}
 
     def load_state_dict(self, s):
         self.sampler.load_state_dict(s["sampler"])
-        self.aug_gen.set_state(s["aug_gen"])
+        self._aug_calls = s.get("aug_calls", 0)
         self.M = None if s["M"] is None else s["M"].to(self.device)
         self._mom_init = s["mom_init"]
         self.round = s["round"]
