@@ -1,0 +1,231 @@
+"""Experiment runner (replaces ``ray.tune.run_experiments`` as used by
+``blades/train.py:380-386``).
+
+``experiments = {name: {run, stop, config, checkpoint_config, local_dir}}``.
+Every grid variant is one *trial*: an Algorithm instance stepped with ``train()``
+until a stop criterion fires (``training_iteration`` reached, or any other
+``stop`` metric ``>=`` its threshold — Tune's semantics, which the YAMLs use as a
+divergence kill switch ``train_loss: 100000``).  Trials write Tune-style result
+files and real checkpoints; ``resume=True`` continues unfinished trials from
+their newest checkpoint.
+
+Scheduling on one 8-GPU node: trials are independent, so with ``gpus_per_trial``
+G' the scheduler keeps ``floor(8 / G')`` trial *processes* in flight, each pinned
+with ``HIP_VISIBLE_DEVICES`` (multi-GPU trials are started through
+``torch.distributed.run``).  ``max_concurrent=1`` and a single-GPU trial run
+in-process.
+"""
+import copy
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+from typing import Any, Dict, List, Optional
+
+from blades_amd.algorithms.registry import _get_algorithm_class
+from blades_amd.constants import DEFAULT_RESULTS_ROOT
+from .grid import expand_grid, variant_tag
+from .loggers import TrialLogger
+
+
+def default_results_root() -> str:
+    return os.environ.get("BLADES_RESULTS_DIR", str(Path.home() / DEFAULT_RESULTS_ROOT))
+
+
+def should_stop(result: Dict[str, Any], stop: Optional[Dict[str, Any]]) -> bool:
+    for k, thr in (stop or {}).items():
+        v = result.get(k)
+        if v is None:
+            continue
+        try:
+            if float(v) >= float(thr) or v != v:  # NaN also stops the trial
+                return True
+        except (TypeError, ValueError):
+            continue
+    return False
+
+
+def make_trials(name: str, spec: Dict[str, Any]) -> List[Dict[str, Any]]:
+    trials = []
+    num_samples = int(spec.get("num_samples", 1))
+    idx = 0
+    for cfg, chosen in expand_grid(spec.get("config", {})):
+        for _ in range(num_samples):
+            tag = variant_tag(chosen)
+            trial_id = f"{idx:05d}"
+            trials.append({
+                "experiment": name, "run": spec["run"], "stop": spec.get("stop", {}), "config": cfg,
+                "checkpoint_config": spec.get("checkpoint_config", {}), "trial_id": trial_id,
+                "dir_name": f"{spec['run']}_{trial_id}" + (f"_{tag}" if tag else ""),
+                "local_dir": spec.get("local_dir") or spec.get("storage_path") or default_results_root(),
+                "gpus_per_trial": _gpus_of(cfg),
+            })
+            idx += 1
+    return trials
+
+
+def _gpus_of(cfg: Dict[str, Any]) -> int:
+    """How many whole GPUs a trial occupies.  The Ray-era fractional requests
+    (``num_gpus_for_driver: 0.25`` = "4 trials per GPU") map to one GPU; an explicit
+    ``num_gpus`` / ``world_size`` key asks for a multi-GPU (RCCL) trial."""
+    n = cfg.get("world_size") or cfg.get("num_gpus") or 0
+    return max(1, int(n)) if n else 1
+
+
+def latest_checkpoint(trial_dir: str) -> Optional[str]:
+    cks = sorted(glob.glob(os.path.join(trial_dir, "checkpoint_*")))
+    cks = [c for c in cks if os.path.exists(os.path.join(c, "algorithm_state.pkl"))]
+    return cks[-1] if cks else None
+
+
+def run_trial(trial: Dict[str, Any], resume: bool = False, verbose: int = 1) -> Dict[str, Any]:
+    """Runs one trial in this process (all ranks of a multi-GPU trial call this)."""
+    from blades_amd.parallel.runtime import get_runtime
+
+    rt = get_runtime()
+    trial_dir = os.path.join(trial["local_dir"], trial["experiment"], trial["dir_name"])
+    done_marker = os.path.join(trial_dir, "DONE")
+    if resume and os.path.exists(done_marker):
+        with open(os.path.join(trial_dir, "result.json")) as f:
+            lines = f.read().strip().splitlines()
+        last = json.loads(lines[-1]) if lines else {}
+        target = (trial.get("stop") or {}).get("training_iteration")
+        if target is None or last.get("training_iteration", 0) >= int(target) or should_stop(
+                last, {k: v for k, v in (trial.get("stop") or {}).items() if k != "training_iteration"}):
+            return last
+        os.unlink(done_marker)  # finished for an earlier, smaller budget: continue
+    cls, _ = _get_algorithm_class(trial["run"], return_config=True)
+    cfg = copy.deepcopy(trial["config"])
+    cfg.pop("world_size", None)
+    algo = cls(config=cfg)
+    ck = latest_checkpoint(trial_dir) if resume else None
+    if ck:
+        algo.load_checkpoint(ck)
+    logger = None
+    if rt.is_main:
+        if not resume and os.path.isdir(trial_dir):
+            shutil.rmtree(trial_dir)
+        logger = TrialLogger(trial_dir, trial["config"], trial["trial_id"], trial["dir_name"])
+    ccfg = trial.get("checkpoint_config") or {}
+    freq = int(ccfg.get("checkpoint_frequency", 0) or 0)
+    at_end = bool(ccfg.get("checkpoint_at_end", False))
+    keep = ccfg.get("num_to_keep")
+    stop = dict(trial.get("stop") or {})
+    result: Dict[str, Any] = {}
+    saved: List[str] = sorted(glob.glob(os.path.join(trial_dir, "checkpoint_*")))
+
+    def save():
+        d = os.path.join(trial_dir, f"checkpoint_{algo.iteration:06d}")
+        algo.save_checkpoint(d)
+        if rt.is_main:
+            saved.append(d)
+            while keep and len(saved) > int(keep):
+                shutil.rmtree(saved.pop(0), ignore_errors=True)
+
+    while True:
+        if "training_iteration" in stop and algo.iteration >= int(stop["training_iteration"]):
+            break
+        result = algo.train()
+        if logger is not None:
+            logger.on_result(result)
+            if verbose:
+                keys = ("training_iteration", "train_loss", "ce_loss", "acc_top_1", "rounds_per_s")
+                msg = " ".join(f"{k}={result[k]:.4g}" if isinstance(result.get(k), float) else f"{k}={result.get(k)}"
+                               for k in keys if k in result)
+                if verbose > 1 or "acc_top_1" in result:
+                    print(f"[{trial['dir_name'][:60]}] {msg}", flush=True)
+        if freq and algo.iteration % freq == 0:
+            save()
+        if should_stop(result, stop):
+            break
+    if at_end:
+        save()
+    if logger is not None:
+        logger.close()
+        Path(done_marker).write_text(time.strftime("%Y-%m-%d %H:%M:%S"))
+    algo.stop()
+    return result
+
+
+class TrialScheduler:
+    """Runs trials as subprocesses pinned to GPUs (see module docstring)."""
+
+    def __init__(self, num_gpus: Optional[int] = None, max_concurrent: Optional[int] = None):
+        if num_gpus is None:
+            try:
+                import torch
+
+                num_gpus = torch.cuda.device_count()
+            except Exception:
+                num_gpus = 0
+        self.num_gpus = num_gpus
+        self.max_concurrent = max_concurrent
+
+    def run(self, trials: List[Dict[str, Any]], resume: bool = False, verbose: int = 1) -> List[int]:
+        free = list(range(max(self.num_gpus, 1)))
+        running = []  # (proc, gpus, trial, specfile)
+        pending = list(trials)
+        rcs = []
+        port = 23456
+        while pending or running:
+            while pending and (self.max_concurrent is None or len(running) < self.max_concurrent):
+                need = pending[0]["gpus_per_trial"] if self.num_gpus else 1
+                if len(free) < need:
+                    break
+                trial = pending.pop(0)
+                gpus = [free.pop(0) for _ in range(need)]
+                spec = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+                json.dump({"trial": trial, "resume": resume, "verbose": verbose}, spec)
+                spec.close()
+                env = dict(os.environ)
+                if self.num_gpus:
+                    env["HIP_VISIBLE_DEVICES"] = ",".join(str(g) for g in gpus)
+                port += 1
+                if need > 1:
+                    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={need}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m",
+                           "blades_amd.tune.trial_worker", spec.name]
+                else:
+                    cmd = [sys.executable, "-m", "blades_amd.tune.trial_worker", spec.name]
+                running.append((subprocess.Popen(cmd, env=env), gpus, trial, spec.name))
+            still = []
+            for proc, gpus, trial, specfile in running:
+                rc = proc.poll()
+                if rc is None:
+                    still.append((proc, gpus, trial, specfile))
+                else:
+                    rcs.append(rc)
+                    free.extend(gpus)
+                    os.unlink(specfile)
+                    if rc != 0:
+                        print(f"[tune] trial {trial['dir_name']} failed with exit code {rc}", file=sys.stderr)
+            running = still
+            if running:
+                time.sleep(0.2)
+        return rcs
+
+
+def run_experiments(experiments: Dict[str, Dict[str, Any]], resume: bool = False, verbose: int = 1,
+                    concurrent: bool = True, max_concurrent: Optional[int] = None, scheduler=None,
+                    in_process: Optional[bool] = None) -> List[Dict[str, Any]]:
+    """Runs every trial of every experiment; returns the trial descriptors
+    (each with ``last_result`` when run in-process)."""
+    from blades_amd.parallel.runtime import get_runtime
+
+    trials: List[Dict[str, Any]] = []
+    for name, spec in experiments.items():
+        trials.extend(make_trials(name, spec))
+    rt = get_runtime()
+    if in_process is None:
+        in_process = rt.distributed or not concurrent or max_concurrent == 1 or len(trials) == 1
+    if in_process:
+        for t in trials:
+            t["last_result"] = run_trial(t, resume=resume, verbose=verbose)
+        return trials
+    TrialScheduler(max_concurrent=max_concurrent).run(trials, resume=resume, verbose=verbose)
+    return trials

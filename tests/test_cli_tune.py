@@ -1,0 +1,103 @@
+"""CLI -> experiment runner -> result files -> checkpoint/resume."""
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import pytest
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def tiny_yaml(path, data_root, iters=4, grid=True):
+    exp = {"tiny": {"run": "FEDAVG", "stop": {"training_iteration": iters, "train_loss": 100000}, "config": {
+        "seed": {"grid_search": [1, 2]} if grid else 1,
+        "dataset_config": {"type": "mnist", "num_clients": 6, "num_classes": 10, "train_batch_size": 8,
+                           "n_train": 200, "n_test": 60, "data_root": data_root, "use_cache": False},
+        "evaluation_interval": 2, "global_model": "mlp", "num_remote_workers": 0, "num_gpus_per_worker": 0,
+        "device": "cpu",
+        "client_config": {"lr": 0.5},
+        "server_config": {"aggregator": {"grid_search": [{"type": "Median"}, {"type": "Trimmedmean"}]} if grid else
+                          {"type": "Centeredclipping"},
+                          "optimizer": {"type": "SGD", "lr": 0.5, "lr_schedule": [[0, 0.5], [2, 0.5], [3, 0.1]],
+                                        "momentum": 0.9}},
+        "num_malicious_clients": 1,
+        "adversary_config": {"type": "blades.adversaries.ALIEAdversary"}}}}
+    with open(path, "w") as f:
+        yaml.safe_dump(exp, f)
+
+
+def cli(args, env_extra=None):
+    env = dict(os.environ, BLADES_SYNTHETIC_DATA="1", PYTHONPATH=ROOT)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, "-m", "blades_amd.train"] + args, env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r
+
+
+def test_grid_file_run_writes_tune_layout(tmp_path):
+    y = tmp_path / "exp.yaml"
+    tiny_yaml(str(y), str(tmp_path / "data"))
+    out = tmp_path / "results"
+    cli(["file", str(y), "--local-dir", str(out), "--local-mode", "--checkpoint-at-end"])
+    trials = sorted(os.listdir(out / "tiny"))
+    assert len(trials) == 4  # 2 seeds x 2 aggregators
+    for t in trials:
+        d = out / "tiny" / t
+        for fn in ("params.json", "params.pkl", "result.json", "progress.csv", "DONE"):
+            assert (d / fn).exists(), fn
+        rows = [json.loads(l) for l in open(d / "result.json")]
+        assert [r["training_iteration"] for r in rows] == [1, 2, 3, 4]
+        assert "acc_top_1" in rows[1] and "acc_top_1" not in rows[0]  # evaluation_interval = 2
+        assert rows[-1]["server lr"] == [0.1]
+        params = pickle.load(open(d / "params.pkl", "rb"))
+        # the contract of tuned_examples/visualization/visualize.py
+        assert params["server_config"]["aggregator"]["type"] in ("Median", "Trimmedmean")
+        assert params["num_malicious_clients"] == 1
+        ck = [c for c in os.listdir(d) if c.startswith("checkpoint_")]
+        assert ck and (d / ck[0] / "algorithm_state.pkl").exists()
+        state = pickle.load(open(d / ck[0] / "algorithm_state.pkl", "rb"))
+        assert "config" in state  # the reference's whole checkpoint; the rest is ours
+        assert state["config"].num_malicious_clients == 1
+
+
+def test_checkpoint_resume_is_exact(tmp_path):
+    """2 rounds + checkpoint + resume for 2 more == 4 rounds straight (stateful aggregator,
+    server momentum, LR schedule, sampler state all restored)."""
+    data = str(tmp_path / "data")
+    y4, y2 = tmp_path / "e4.yaml", tmp_path / "e2.yaml"
+    tiny_yaml(str(y4), data, iters=4, grid=False)
+    tiny_yaml(str(y2), data, iters=2, grid=False)
+    a, b = tmp_path / "A", tmp_path / "B"
+    cli(["file", str(y4), "--local-dir", str(a), "--local-mode"])
+    cli(["file", str(y2), "--local-dir", str(b), "--local-mode", "--checkpoint-freq", "2"])
+    cli(["file", str(y4), "--local-dir", str(b), "--local-mode", "--resume"])
+    ta, tb = os.listdir(a / "tiny")[0], os.listdir(b / "tiny")[0]
+    ra = [json.loads(l) for l in open(a / "tiny" / ta / "result.json")]
+    rb = [json.loads(l) for l in open(b / "tiny" / tb / "result.json")]
+    assert [r["training_iteration"] for r in rb] == [1, 2, 3, 4]
+    for x, yv in zip(ra, rb):
+        assert abs(x["train_loss"] - yv["train_loss"]) < 1e-6
+    assert abs(ra[-1]["acc_top_1"] - rb[-1]["acc_top_1"]) < 1e-9
+    assert abs(ra[-1]["ce_loss"] - rb[-1]["ce_loss"]) < 1e-6
+
+
+def test_run_callback_flags(tmp_path):
+    cfg = {"dataset_config": {"type": "mnist", "num_clients": 4, "num_classes": 10, "train_batch_size": 8,
+                              "n_train": 100, "n_test": 40, "data_root": str(tmp_path / "d"), "use_cache": False},
+           "global_model": "mlp", "device": "cpu", "evaluation_interval": 1}
+    cli(["--algo", "FEDAVG", "--config", json.dumps(cfg), "--stop", '{"training_iteration": 2}', "--local-dir",
+         str(tmp_path / "r")])
+    t = os.listdir(tmp_path / "r" / "default")[0]
+    assert len(open(tmp_path / "r" / "default" / t / "result.json").read().strip().splitlines()) == 2
+
+
+def test_stop_on_metric_threshold():
+    from blades_amd.tune import should_stop
+
+    assert should_stop({"train_loss": 1e6}, {"train_loss": 100000})
+    assert not should_stop({"train_loss": 2.0}, {"train_loss": 100000, "training_iteration": 10})
+    assert should_stop({"train_loss": float("nan")}, {"train_loss": 100000})
