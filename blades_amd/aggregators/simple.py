@@ -78,7 +78,8 @@ class GeoMed(Aggregator):
             w0 = weights.to(device=U.device, dtype=torch.float32)
         median = ops.weighted_col_sum(U, w0 / w0.sum())
         dist = self._dist(U, median, ctx)
-        obj = (dist * w0).sum() / w0.sum()
+        w0d = w0.double()
+        obj = (dist.double() * w0d).sum() / w0d.sum()  # fp64 scalar like the reference's numpy average
         new_w = w0
         # `done` freezes the iterate on the device once converged, so checking
         # the flag only every few iterations does not change the result.
@@ -88,7 +89,7 @@ class GeoMed(Aggregator):
             cand_w = w0 / dist.clamp_min(self.eps)
             cand_m = ops.weighted_col_sum(U, cand_w / cand_w.sum())
             cand_dist = self._dist(U, cand_m, ctx)
-            cand_obj = (cand_dist * w0).sum() / w0.sum()
+            cand_obj = (cand_dist.double() * w0d).sum() / w0d.sum()
             keep = done
             median = torch.where(keep, median, cand_m)
             dist = torch.where(keep, dist, cand_dist)

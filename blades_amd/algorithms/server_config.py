@@ -54,7 +54,7 @@ class ServerConfig:
         for key, value in config_dict.items():
             if key == "lr":
                 self.optimizer.update(lr=value)
-            if key in ("aggregator", "optimizer"):
+            elif key in ("aggregator", "optimizer"):
                 self.training(**{key: value})
             else:
                 if not hasattr(self, key) and log_once("unknown_property_in_server_config_" + key):

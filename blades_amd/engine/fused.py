@@ -345,7 +345,10 @@ def build_template(model: nn.Module, sink: GradSink) -> nn.Module:
             else:
                 swap(child)
 
-    swap(tmpl)
+    holder = nn.Module()
+    holder.root = tmpl
+    swap(holder)  # also handles a model that is itself a single leaf layer
+    tmpl = holder.root
     from blades_amd.models import resnet as _rn
 
     if isinstance(tmpl, _rn.ResNet):
