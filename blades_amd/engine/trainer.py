@@ -372,10 +372,9 @@ class ClientEngine:
         every rank ends up with ``[K, D]``."""
         if not self.ctx.distributed:
             return self.U_row[:, : self.D]
-        rows = self.plan.rows_per_rank()
-        parts = [torch.empty(k, self.Dpad, device=self.device) for k in rows]
-        dist.all_gather(parts, self.U_row)
-        return torch.cat(parts, dim=0)[:, : self.D]
+        from blades_amd.parallel.communicator import all_gather_uneven_rows
+
+        return all_gather_uneven_rows(self.U_row, self.plan.rows_per_rank())[:, : self.D]
 
     # -- masks in row order ------------------------------------------------
     def row_mask(self, flags: List[bool]) -> torch.Tensor:
