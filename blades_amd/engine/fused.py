@@ -391,5 +391,23 @@ class FusedFedSGD:
         return losses.detach()
 
 
+    @torch.no_grad()
+    def forward_only(self, X: torch.Tensor) -> torch.Tensor:
+        """Evaluation forward of a chunk: X [Kc, m, ...] -> logits [Kc, m, classes] (fp32).
+        ``eval()`` mode (dropout off); BN still uses per-client batch statistics, like the reference's
+        ``track_running_stats=False`` models do in eval."""
+        Kc, m = X.shape[0], X.shape[1]
+        self.sink.begin(None, None, Kc, m)
+        x = X.reshape(Kc * m, *X.shape[2:])
+        if self.amp_dtype is not None:
+            x = x.to(self.amp_dtype)
+        if x.dim() == 4 and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
+        self.template.eval()
+        out = self.template(x).float().reshape(Kc, m, -1)
+        self.template.train()
+        return out
+
+
 def _identity(z):
     return z

@@ -399,7 +399,7 @@ class ClientEngine:
             with _autocast(self.device, self.amp_dtype):
                 return functional_call(self.model, params, (x,)).float()
 
-        vf = vmap(fwd, in_dims=0, randomness="different")
+        vf = self.fused.forward_only if self.fused is not None else vmap(fwd, in_dims=0, randomness="different")
         by_len: Dict[int, List[int]] = {}
         for r, n in enumerate(st.lengths):
             by_len.setdefault(int(n), []).append(r)
