@@ -40,7 +40,7 @@ _col_stats = _sig("blades_col_stats", [_P, c_long, c_int, c_long, _P, _P, _P, _P
                                        c_int, _P, _P])
 _set_rows = _sig("blades_set_rows", [_P, c_long, c_long, _P, c_int, _P, _P])
 _row_scale = _sig("blades_row_scale", [_P, c_long, c_int, c_long, _P, _P])
-_col_order_stat = _sig("blades_col_order_stat", [_P, c_long, c_int, c_long, _P, c_int, c_int, _P, _P], c_int)
+_col_order_stat = _sig("blades_col_order_stat", [_P, c_long, c_int, c_long, _P, c_int, c_int, c_int, _P, _P], c_int)
 _row_chunks = _sig("blades_row_chunks", [c_long], c_int)
 _row_reduce = _sig("blades_row_reduce", [_P, c_long, c_int, c_long, c_long, _P, c_int, _P, _P, _P, _P, _P])
 _server_step = _sig("blades_server_step", [_P, _P, _P, c_long, c_float, c_float, c_int, _P])
@@ -161,13 +161,42 @@ def row_scale_(U, s):
     return U
 
 
+def _order_stat_fill(mask, K: int, mode: int):
+    """Pad table for the order-statistic kernel: 0 = live row, otherwise the value sorted in its place.
+
+    Median mode alternates +inf / -inf over the dead slots (rows masked out and the rows up to the next
+    power of two) so the two medians always sit in the middle of the sorted block; trimmed-mean mode pads
+    with +inf only.  The live-row count rides in the extra last slot so no host sync is needed.
+    """
+    N = 64
+    while N < K:
+        N *= 2
+    dev = mask.device
+    dead = torch.ones(N, dtype=torch.bool, device=dev)
+    dead[:K] = mask == 0
+    inf = torch.full((), float("inf"), device=dev)
+    if mode == 0:
+        pad = torch.where(torch.cumsum(dead, 0) % 2 == 1, inf, -inf)
+    else:
+        pad = inf.expand(N)
+    fill = torch.empty(N + 1, device=dev)
+    fill[:N] = torch.where(dead, pad, torch.zeros((), device=dev))
+    fill[N] = (K - dead[:K].sum()).to(torch.float32)
+    return fill
+
+
 def col_order_stat(U, mask, mode: int, b: int):
     K, Dl, ld = _chk_matrix(U)
     mask = _vec(mask, K, U.device, name="mask")
+    if mode == 1 and mask is None and not 0 <= 2 * b < K:
+        raise ValueError(f"trimmed mean needs 0 <= 2*b < K, got b={b}, K={K}")
+    fill = None if mask is None else _order_stat_fill(mask, K, mode)
     out = torch.empty(Dl, device=U.device)
-    rc = _col_order_stat(_ptr(U), ld, K, Dl, _ptr(mask), mode, b, _ptr(out), _stream())
-    if rc != 0:
+    rc = _col_order_stat(_ptr(U), ld, K, Dl, _ptr(fill), K, mode, b, _ptr(out), _stream())
+    if rc == 1:
         raise ValueError(f"col_order_stat supports up to 2048 rows, got {K}")
+    if rc != 0:
+        raise ValueError(f"col_order_stat rejected the call (code {rc}): K={K}, ld={ld}, Dl={Dl}, b={b}")
     return out
 
 
