@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--amp", default="bf16")
     ap.add_argument("--samples-per-client", type=int, default=128)
     ap.add_argument("--cpu", action="store_true", help="debug: run on CPU/gloo")
+    ap.add_argument("--torch-profile", default=None,
+                    help="after the timed rounds, run one more under torch.profiler and write the op table here")
     args = ap.parse_args()
 
     import torch
@@ -132,6 +134,18 @@ def main():
             "train_loss": last.get("train_loss") if last else None,
         }
         print(json.dumps(out), flush=True)
+    if args.torch_profile and rt.is_main:
+        from torch.profiler import ProfilerActivity, profile
+
+        acts = [ProfilerActivity.CPU] + ([ProfilerActivity.CUDA] if rt.device.type == "cuda" else [])
+        with profile(activities=acts, record_shapes=True) as prof:
+            algo.train()
+            sync()
+        key = "self_cuda_time_total" if rt.device.type == "cuda" else "self_cpu_time_total"
+        with open(args.torch_profile, "w") as fh:
+            fh.write(prof.key_averages(group_by_input_shape=True).table(sort_by=key, row_limit=80,
+                                                                         max_name_column_width=60,
+                                                                         max_shapes_column_width=90))
     from blades_amd.parallel.runtime import shutdown_runtime
 
     shutdown_runtime()

@@ -384,7 +384,7 @@ def pcbn_backward(x, gy, y, gamma, mean, invstd, Kc: int, coef, U_block, off_gam
 # ---------------------------------------------------------------------------
 # per-client conv weight gradient
 _conv_wgrad = _sig("blades_conv_wgrad", [_P, _P, _P, c_long, c_long, _P, c_int] + [c_int] * 11 + [_P] + [c_int] * 5
-                   + [_P, c_int, c_int, c_long, _P], c_int)
+                   + [_P, c_int, c_int, c_long, c_int, _P], c_int)
 _wgrad_plans = {}
 
 
@@ -463,7 +463,7 @@ def conv_wgrad_supported(x, gy, ks, stride, pad, dilation) -> bool:
     if not (x.is_cuda and x.dtype == torch.bfloat16 and gy.dtype == torch.bfloat16 and x.dim() == 4):
         return False
     Cin, Cout = x.shape[1], gy.shape[1]
-    if Cin % 16 or Cout % 16 or ks[0] != ks[1] or ks[0] not in (1, 3) or stride[0] != stride[1] \
+    if (Cin % 16 and Cin > 16) or Cout % 16 or ks[0] != ks[1] or ks[0] not in (1, 3) or stride[0] != stride[1] \
             or stride[0] not in (1, 2) or pad[0] != pad[1] or tuple(dilation) != (1, 1):
         return False
     if stride[0] == 2 and (x.shape[3] + 2 * pad[0]) % 2:
@@ -487,6 +487,12 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
     if K != Kc or off < 0 or off + numel > Dl:
         raise ValueError("conv_wgrad_: update-matrix block does not match")
     coef = _vec(coef, Kc, x.device, name="coef")
+    cin_store = Cin
+    if Cin % 16:
+        # the stem (3 input channels): zero-pad to one 16-channel MFMA block; only the real channels are stored
+        xp = x.new_zeros((N, H, W, 16)).permute(0, 3, 1, 2)  # channels-last storage
+        xp[:, :Cin] = x
+        x, Cin = xp, 16
     x_client_stride = B * H * W * Cin
     rmul, cmul = W, 1
     if ks == 1 and pad == 0 and stride > 1:
@@ -512,7 +518,7 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
         scratch = _scratch(split * Kc * numel, x.device)
     rc = _conv_wgrad(_ptr(x), _ptr(gy), _ptr(U_block), ld, off, _ptr(coef), int(accumulate), Kc, B, H, W, Cin, Ho,
                      Wo, Cout, ks, stride, pad, _ptr(plan["table"]), plan["nsteps"], plan["nlines"], plan["wslots"],
-                     tmt, split, _ptr(scratch), rmul, cmul, x_client_stride, _stream())
+                     tmt, split, _ptr(scratch), rmul, cmul, x_client_stride, cin_store, _stream())
     if rc == 3:  # staging does not fit in LDS
         return False
     if rc != 0:

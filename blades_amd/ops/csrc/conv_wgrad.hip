@@ -3,7 +3,8 @@
 //   dW_c[co][ci][r][s] = coef[c] * sum_{b,oh,ow} gy[c,b,oh,ow,co] * x[c,b, oh*st+r-pad, ow*st+s-pad, ci]
 //
 // x / gy are channels-last bf16 activations of a client-major batch ([Kc*B, H, W, C]); the
-// result is fp32 in PyTorch weight order at U[c*ld + off + ((co*Cin+ci)*KS + r)*KS + s].
+// result is fp32 in PyTorch weight order at U[c*ld + off + ((co*Cin+ci)*KS + r)*KS + s]  (Cin there = the
+// layer's real channel count `cin_store`; the stem's 3 channels arrive zero-padded to 16).
 // This is the one genuinely per-client GEMM of the FedSGD fast path:
 // M = Cout, N = Cin*taps, reduction = the client's B*Ho*Wo pixels.
 //
@@ -59,6 +60,7 @@ struct WgradParams {
   long x_client_stride;  // elements between two clients' inputs
   int rmul, cmul;       // virtual pixel (row, col) -> physical pixel index row*rmul + col*cmul (1x1 strided convs
                         // are run as stride-1 on the subsampled input without copying it)
+  int Cs;               // input channels actually stored (< Cin when x was zero-padded to a multiple of 16)
   int ablate;           // diagnostics only: bit0 skip staging after the prologue, bit1 skip MFMA work
 };
 
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = co0 + m * 16 + g * 4 + q;
-        if (co < p.Cout && ci < p.Cin) {
-          float* dst = row + ((size_t)co * p.Cin + ci) * TAPS;
+        if (co < p.Cout && ci < p.Cs) {
+          float* dst = row + ((size_t)co * p.Cs + ci) * TAPS;
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
             const float v = cf * acc[m][t][q];
@@ -305,9 +307,10 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
                                  int accumulate, int Kc, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
                                  int ks, int stride, int pad, const int* table, int nsteps, int nlines, int wslots,
                                  int tmt, int split, float* scratch, int rmul, int cmul,
-                                 long x_client_stride, hipStream_t st) {
+                                 long x_client_stride, int cin_store, hipStream_t st) {
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || Cin % 16 || Cout % 16) return 1;
   if (nlines & (nlines - 1)) return 2;
+  if (cin_store < 1 || cin_store > Cin) return 7;
   WgradParams p;
   p.x = (const unsigned short*)x; p.gy = (const unsigned short*)gy; p.U = U; p.ld = ld; p.off = off;
   p.coef = coef; p.table = table; p.accumulate = accumulate;
@@ -316,7 +319,8 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
   p.rmul = rmul; p.cmul = cmul; p.x_client_stride = x_client_stride;
   p.w_shift = -1;
   for (int b = 0; b < 16; ++b) if ((1 << b) == W) p.w_shift = b;
-  p.split = split < 1 ? 1 : split; p.scratch = scratch; p.numel = (long)Cout * Cin * ks * ks; p.Kc = Kc;
+  p.split = split < 1 ? 1 : split; p.scratch = scratch; p.numel = (long)Cout * cin_store * ks * ks; p.Kc = Kc;
+  p.Cs = cin_store;
   if (p.split > 1 && scratch == nullptr) return 6;
   { const char* e = getenv("BLADES_WGRAD_ABLATE"); p.ablate = e ? atoi(e) : 0; }
   if (Cout % (tmt * 16)) return 4;

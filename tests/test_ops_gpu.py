@@ -266,6 +266,8 @@ def test_fused_engine_gpu_matches_fp32_reference(dev, tmp_path):
     (2, 4, 256, 512, 8, 1, 2, 0),
     (2, 2, 32, 64, 13, 3, 1, 0),
     (1, 5, 16, 48, 11, 3, 1, 1),
+    (3, 4, 3, 64, 32, 3, 1, 1),
+    (2, 4, 1, 32, 28, 3, 1, 1),
 ])
 def test_conv_wgrad_kernel(dev, Kc, B, Cin, Cout, H, ks, stride, pad):
     import torch.nn.functional as F
