@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--aggregator", default="Median")
     ap.add_argument("--adversary", default="ALIEAdversary")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=100, help="clients vectorised per kernel chunk")
+    ap.add_argument("--chunk", type=int, default=200, help="clients vectorised per kernel chunk")
     ap.add_argument("--amp", default="bf16")
     ap.add_argument("--samples-per-client", type=int, default=128)
     ap.add_argument("--cpu", action="store_true", help="debug: run on CPU/gloo")
@@ -60,6 +60,10 @@ def main():
     K = args.clients
     f = int(round(args.malicious_frac * K))
     agg = {"type": args.aggregator}
+    chunk = args.chunk
+    if world > 1:
+        # at least two chunks per rank, so the all-to-all of the first overlaps the training of the second
+        chunk = max(1, min(chunk, -(-(K - f) // (2 * world))))
     root = tempfile.mkdtemp(prefix="blades_bench_")
     cfg = (FedavgConfig()
            .resources(num_gpus_for_driver=0 if args.cpu else 1)
@@ -73,7 +77,7 @@ def main():
            .adversary(num_malicious_clients=f,
                       adversary_config={"type": f"blades.adversaries.{args.adversary}"})
            .evaluation(evaluation_interval=0)
-           .engine(clients_per_chunk=args.chunk, amp_dtype=None if args.amp == "fp32" else args.amp))
+           .engine(clients_per_chunk=chunk, amp_dtype=None if args.amp == "fp32" else args.amp))
     algo = cfg.build()
 
     def sync():

@@ -304,6 +304,10 @@ class ClientEngine:
         nontrain = [r for r in range(self.Kloc) if not self._trains[r]]
         if nontrain:
             self.U_row[torch.as_tensor(nontrain, device=dev)] = 0
+        # rows whose content is final only at the end of the round (sequential clients, round-end hooks):
+        # with any of those the exchange cannot start early
+        late = bool(seq) or self._has_round_end_hooks()
+        self._exchange_begin()
         with torch.enable_grad():
             for c0 in range(0, len(batched), self.chunk):
                 ks = np.array(batched[c0: c0 + self.chunk], dtype=np.int64)
@@ -315,6 +319,9 @@ class ClientEngine:
                 benign = torch.tensor([not self._malicious[r] for r in rows], device=dev)
                 loss_sum += (losses.double() * benign).sum()
                 loss_cnt += benign.sum()
+                if not late and c0 + self.chunk < len(batched):
+                    # everything below the next untrained row is final: ship it while the next chunk trains
+                    self._exchange_upto(int(self._train_rows[batched[c0 + self.chunk]]))
         for k in seq:
             r = int(self._train_rows[k])
             l = self._train_sequential(theta, r)
@@ -325,7 +332,8 @@ class ClientEngine:
         self._post_round_hooks()
         self.timers["local_train_s"] = time.perf_counter() - t0
         t1 = time.perf_counter()
-        U = self.exchange()
+        self._exchange_upto(self.Kloc)
+        U = self._exchange_finish()
         if self.ctx.distributed:
             pack = torch.stack([loss_sum, loss_cnt])
             self.ctx.all_reduce(pack)
@@ -334,10 +342,16 @@ class ClientEngine:
         self.round += 1
         return U, loss_sum, loss_cnt
 
+    def _round_end_rows(self):
+        return [r for r in self._train_rows if self._specs[r] and (
+            "update_clip" in self._specs[r] or self._specs[r].get("update_noise_std", 0) > 0)]
+
+    def _has_round_end_hooks(self) -> bool:
+        return bool(self._round_end_rows())
+
     def _post_round_hooks(self):
         """Fused ``on_train_round_end`` effects: update clip + DP noise."""
-        rows = [r for r in self._train_rows if self._specs[r] and (
-            "update_clip" in self._specs[r] or self._specs[r].get("update_noise_std", 0) > 0)]
+        rows = self._round_end_rows()
         if not rows:
             return
         rt = torch.as_tensor(rows, device=self.device)
@@ -355,16 +369,70 @@ class ClientEngine:
 
     # ------------------------------------------------------------------
     def exchange(self) -> torch.Tensor:
-        """Row shard -> column shard (all-to-all over RCCL / xGMI)."""
+        """Row shard -> column shard (all-to-all over RCCL / xGMI), in one go."""
+        self._exchange_begin()
+        self._exchange_upto(self.Kloc)
+        return self._exchange_finish()
+
+    # The all-to-all is issued in ``P`` pieces of consecutive local rows so that finished rows travel while
+    # later chunks still train (SURVEY §5.8: "a dedicated comm stream overlapping the all-to-all of finished
+    # client chunks with the training of the next chunk").  Every piece is one grouped batch of point-to-point
+    # sends/receives to all peers — xGMI is a full mesh, so all 7 links of a GPU carry data at once — and
+    # lands directly in the receiver's rows of ``U_col``.  All ranks issue the same ``P`` batches in the same
+    # order; which rows a piece covers follows from the (globally known) rows-per-rank table alone.
+    def _piece_bounds(self, k_rank: int, j: int):
+        P = self._n_pieces
+        return (j * k_rank) // P, ((j + 1) * k_rank) // P
+
+    def _exchange_begin(self):
+        if not self.ctx.distributed:
+            return
+        rows = self.plan.rows_per_rank()
+        self._n_pieces = max(1, -(-max(rows) // self.chunk))
+        self._next_piece = 0
+        self._works = []
+        self._send_keep = []
+        self.ctx.stats["alltoall_bytes"] = 0
+
+    def _exchange_upto(self, ready_rows: int):
+        """Issue (asynchronously) every not-yet-sent piece that lies entirely below local row ``ready_rows``."""
+        if not self.ctx.distributed:
+            return
+        G, me, Dl = self.rt.world_size, self.rt.rank, self.Dl
+        rows = self.plan.rows_per_rank()
+        row_off = np.concatenate([[0], np.cumsum(rows)])
+        while self._next_piece < self._n_pieces:
+            j = self._next_piece
+            a, b = self._piece_bounds(self.Kloc, j)
+            if b > ready_rows:
+                break
+            self._next_piece += 1
+            ops_ = []
+            if b > a:
+                # pack [rows, G*Dl] -> [G, rows, Dl]: one contiguous message per peer
+                send = self.U_row[a:b].view(b - a, G, Dl).transpose(0, 1).contiguous()
+                self._send_keep.append(send)
+                self.U_col[row_off[me] + a: row_off[me] + b].copy_(send[me])
+                for q in range(G):
+                    if q != me:
+                        ops_.append(dist.P2POp(dist.isend, send[q], q))
+                self.ctx.stats["alltoall_bytes"] += (G - 1) * (b - a) * Dl * 4
+            for q in range(G):
+                if q == me:
+                    continue
+                qa, qb = self._piece_bounds(rows[q], j)
+                if qb > qa:
+                    ops_.append(dist.P2POp(dist.irecv, self.U_col[row_off[q] + qa: row_off[q] + qb], q))
+            if ops_:
+                self._works.extend(dist.batch_isend_irecv(ops_))
+
+    def _exchange_finish(self) -> torch.Tensor:
         if not self.ctx.distributed:
             return self.U_row
-        G = self.rt.world_size
-        send = self.U_row.view(self.Kloc, G, self.Dl).transpose(0, 1).contiguous()
-        rows = self.plan.rows_per_rank()
-        in_splits = [self.Kloc * self.Dl] * G
-        out_splits = [k * self.Dl for k in rows]
-        dist.all_to_all_single(self.U_col.view(-1), send.view(-1), out_splits, in_splits)
-        self.ctx.stats["alltoall_bytes"] = send.numel() * 4
+        assert self._next_piece == self._n_pieces, "exchange finished before every piece was issued"
+        for w in self._works:
+            w.wait()
+        self._works, self._send_keep = [], []
         return self.U_col
 
     def gather_full(self) -> torch.Tensor:
