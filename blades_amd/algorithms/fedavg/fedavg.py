@@ -45,6 +45,19 @@ class FedavgConfig(AlgorithmConfig):
         super().__init__(algo_class=algo_class or Fedavg)
         self.adversary_config = {}
         self.num_malicious_clients = 0
+        # fault tolerance (the reference has none of its own)
+        self.guard_rows = False        # zero client rows that contain NaN/Inf before attack + aggregation
+        self.fault_injection = None    # test hook: dict or list of dicts, see Fedavg._inject_faults
+
+    def fault_tolerance(self, *, guard_rows: Optional[bool] = NotProvided, fault_injection=NotProvided):
+        """``guard_rows``: drop (zero) update rows with non-finite entries.  ``fault_injection``: one or more
+        ``{"round": r, "kind": "nan_row" | "inf_row" | "scale_row" | "kill_rank", "row": i, "rank": k,
+        "value": v}`` events, also settable through the ``BLADES_INJECT_FAULT`` environment variable (JSON)."""
+        if guard_rows is not NotProvided:
+            self.guard_rows = bool(guard_rows)
+        if fault_injection is not NotProvided:
+            self.fault_injection = fault_injection
+        return self
 
     def adversary(self, *, num_malicious_clients: Optional[int] = NotProvided,
                   adversary_config: Optional[Dict] = NotProvided):
@@ -200,6 +213,10 @@ class Fedavg(Algorithm):
         with T("local_train"):
             U, loss_sum, loss_cnt = self.engine.train_round(self.server.theta)
         self.update_matrix = U
+        self._inject_faults(U)
+        if getattr(self.config, "guard_rows", False):
+            with T("guard_rows"):
+                self._guard_rows(U)
         with T("attack"):
             if self.adversary.uses_local_results:
                 if self.ctx.distributed:
@@ -224,10 +241,69 @@ class Fedavg(Algorithm):
             results["num_selected_clients"] = int(info["num_selected"])
         return results
 
+    # -- fault injection / detection ---------------------------
+    def _fault_events(self):
+        ev = getattr(self.config, "fault_injection", None)
+        import json
+        import os
+
+        env = os.environ.get("BLADES_INJECT_FAULT")
+        evs = [] if ev is None else (list(ev) if isinstance(ev, (list, tuple)) else [ev])
+        if env:
+            e = json.loads(env)
+            evs += e if isinstance(e, list) else [e]
+        return evs
+
+    def _inject_faults(self, U: torch.Tensor):
+        """Test hook: corrupt a row of the update matrix or kill a rank at a given round (1-based, the round
+        that is being computed).  Row indices are global rows of the column-sharded matrix, so every rank
+        applies the corruption to its own column slice."""
+        events = self._fault_events()
+        if not events:
+            return
+        rnd = self._counters[NUM_GLOBAL_STEPS] + 1
+        for e in events:
+            if int(e.get("round", -1)) != rnd:
+                continue
+            kind = e.get("kind", "nan_row")
+            if kind == "kill_rank":
+                if self.rt.rank == int(e.get("rank", 0)):
+                    import os
+
+                    print(f"[fault-injection] rank {self.rt.rank} exits at round {rnd}", flush=True)
+                    os._exit(int(e.get("code", 17)))
+                continue
+            row = int(e.get("row", 0))
+            if kind == "nan_row":
+                U[row].fill_(float("nan"))
+            elif kind == "inf_row":
+                U[row].fill_(float("inf"))
+            elif kind == "scale_row":
+                U[row].mul_(float(e.get("value", 1e30)))
+            else:
+                raise ValueError(f"unknown fault kind {kind!r}")
+
+    def _guard_rows(self, U: torch.Tensor):
+        """Zero every client row that holds a non-finite value.  The verdict comes from the row norms (one
+        streaming pass over ``U`` + one ``[K]`` all-reduce — NaN/Inf propagate through the sum, so every rank
+        agrees); only flagged rows are rewritten.  Costs one host sync per round, which is why it is opt-in.
+        ``self.dropped_rows`` keeps the count of the last round."""
+        from blades_amd import ops
+
+        sq = ops.row_sqnorm(U)
+        if self.ctx.distributed:
+            self.ctx.all_reduce(sq)
+        bad = (~torch.isfinite(sq)).nonzero().flatten()
+        self.dropped_rows = int(bad.numel())
+        if self.dropped_rows:
+            U[bad] = 0.0
+
     def evaluate(self):
         with self._timers("evaluate"):
             r = self.engine.evaluate(self.server.theta)
-        return {"ce_loss": r["ce_loss"], "acc_top_1": r["acc_top_1"]}
+        # reference returns ce_loss + acc_top_1 (fedavg.py:268-277); the other top-k accuracies of its Task
+        # metric collection (task.py:104-121) come out of the same fused kernel for free
+        return {k: v for k, v in r.items() if k == "ce_loss" or k.startswith("acc_top_")}
 
     # -- checkpoint -----------------------------------------------------
     def __getstate__(self) -> Dict:

@@ -461,7 +461,10 @@ class ClientEngine:
         bs = self.dataset.test_bs
         tf = self.dataset.test_transform
         st = self.test_store
-        acc = torch.zeros(3, device=self.device, dtype=torch.float64)  # ce_sum, correct, n
+        ncls = int(getattr(self.dataset, "num_classes", 10) or 10)
+        ks = tuple(k for k in (1, 3, 5, 7, 9) if k < ncls) or (1,)  # reference: top-1/3/5/7/9 for 10 classes
+        acc = torch.zeros(1 + len(ks), device=self.device, dtype=torch.float64)  # ce_sum, hits@k...
+        count = 0
 
         def fwd(x):
             with _autocast(self.device, self.amp_dtype):
@@ -485,15 +488,16 @@ class ClientEngine:
                     if tf is not None:
                         X = tf(X)
                     logits = vf(X)
-                    ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), Y.reshape(-1),
-                                                           reduction="sum")
-                    correct = (logits.argmax(-1) == Y).sum()
-                    acc += torch.stack([ce.double(), correct.double(), torch.tensor(float(Y.numel()),
-                                                                                  device=self.device,
-                                                                                  dtype=torch.float64)])
+                    acc += ops.ce_topk(logits.reshape(-1, logits.shape[-1]), Y.reshape(-1), ks)  # fused CE + top-k
+                    count += Y.numel()
+        acc = torch.cat([acc, torch.tensor([float(count)], device=self.device, dtype=torch.float64)])
         self.ctx.all_reduce(acc)
-        ce, correct, n = acc.tolist()
-        return {"ce_loss": ce / max(n, 1.0), "acc_top_1": correct / max(n, 1.0), "num_test_samples": int(n)}
+        vals = acc.tolist()
+        n = max(vals[-1], 1.0)
+        out = {"ce_loss": vals[0] / n, "num_test_samples": int(vals[-1])}
+        for k, h in zip(ks, vals[1:-1]):
+            out[f"acc_top_{k}"] = h / n
+        return out
 
     # -- checkpoint -------------------------------------------------------
     def state_dict(self):

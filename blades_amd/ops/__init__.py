@@ -182,3 +182,10 @@ def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, over
 def power_iteration_top(G, iters=8):
     # K x K linear algebra (K = clients): library GEMMs on either device.
     return ref.power_iteration_top(G, iters)
+
+
+def ce_topk(logits, labels, ks=(1,)):
+    """Summed CE + top-k hit counts -> float64 ``[1 + len(ks)]`` (one fused kernel on the GPU)."""
+    if logits.is_cuda and not _FORCE_REFERENCE:
+        return _h().ce_topk(logits, labels, tuple(int(k) for k in ks))
+    return ref.ce_topk(logits, labels, ks)

@@ -524,3 +524,41 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
     if rc != 0:
         raise ValueError(f"conv_wgrad_: unsupported configuration (rc={rc})")
     return True
+
+
+# ---------------------------------------------------------------------------
+# fused evaluation metrics
+_ce_topk = _sig("blades_ce_topk", [_P, c_long, _P, c_long, c_int, _P, c_int, _P, c_int, _P, _P], c_int)
+_ks_cache = {}
+
+
+def ce_topk(logits, labels, ks):
+    lg = logits.reshape(-1, logits.shape[-1])
+    if lg.dtype != torch.float32:
+        lg = lg.float()
+    if lg.stride(1) != 1:
+        lg = lg.contiguous()
+    y = labels.reshape(-1)
+    if y.dtype != torch.int64:
+        y = y.long()
+    y = y.contiguous()
+    N, C = lg.shape
+    if y.numel() != N:
+        raise ValueError(f"ce_topk: {N} logit rows but {y.numel()} labels")
+    if len(ks) > 8:
+        raise ValueError("ce_topk: at most 8 values of k")
+    import ctypes
+
+    karr = _ks_cache.get(ks)
+    if karr is None:
+        karr = (ctypes.c_int * max(1, len(ks)))(*ks)
+        _ks_cache[ks] = karr
+    out = torch.zeros(1 + len(ks), dtype=torch.float64, device=lg.device)
+    if N == 0:
+        return out
+    part = torch.empty(((N + 255) // 256) * 9, dtype=torch.float64, device=lg.device)
+    rc = _ce_topk(_ptr(lg), lg.stride(0), _ptr(y), N, C, ctypes.cast(karr, c_void_p), len(ks), _ptr(part), 0,
+                  _ptr(out), _stream())
+    if rc != 0:
+        raise ValueError(f"ce_topk rejected the call (code {rc})")
+    return out

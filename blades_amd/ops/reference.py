@@ -260,3 +260,17 @@ def power_iteration_top(G: torch.Tensor, iters: int = 8) -> torch.Tensor:
         w = G @ v
         v = w / w.norm().clamp_min(1e-30)
     return v
+
+
+def ce_topk(logits: torch.Tensor, labels: torch.Tensor, ks=(1,)) -> torch.Tensor:
+    """float64 ``[1 + len(ks)]``: summed cross-entropy, then the number of samples whose target class is among
+    the ``k`` best logits (ties go to the lower class index) for every ``k`` in ``ks``
+    (reference metrics: ``fllib/tasks/task.py:104-121``)."""
+    lg = logits.float().reshape(-1, logits.shape[-1])
+    y = labels.reshape(-1).long()
+    ce = torch.nn.functional.cross_entropy(lg, y, reduction="sum").double()
+    ly = lg.gather(1, y[:, None])
+    cls = torch.arange(lg.shape[1], device=lg.device)[None, :]
+    rank = ((lg > ly) | ((lg == ly) & (cls < y[:, None]))).sum(1)
+    hits = [(rank < int(k)).sum().double() for k in ks]
+    return torch.stack([ce] + hits)

@@ -299,3 +299,25 @@ def test_conv_wgrad_kernel(dev, Kc, B, Cin, Cout, H, ks, stride, pad):
     # accumulate mode
     assert h.conv_wgrad_(x, gy, Kc, U, 5, coef, True, ks, stride, pad)
     torch.testing.assert_close(U[:, 5:5 + n].reshape(Kc, Cout, Cin, ks, ks), 2 * ref, rtol=2e-3, atol=4e-3 * scale)
+
+
+@pytest.mark.parametrize("N,C", [(1, 10), (300, 10), (1000, 10), (257, 100), (64, 3)])
+def test_ce_topk(dev, N, C):
+    from blades_amd import ops
+    from blades_amd.ops import reference as ref
+
+    g = torch.Generator().manual_seed(N * 31 + C)
+    lg = (torch.randn(N, C, generator=g) * 3).to(dev)
+    lg[::7, 0] = lg[::7, min(2, C - 1)]  # exact ties
+    y = torch.randint(0, C, (N,), generator=g).to(dev)
+    ks = tuple(k for k in (1, 3, 5, 7, 9) if k < C)
+    out = ops.ce_topk(lg, y, ks)
+    exp = ref.ce_topk(lg, y, ks)
+    assert out.dtype == torch.float64
+    torch.testing.assert_close(out[0], exp[0], rtol=1e-5, atol=1e-4)
+    assert torch.equal(out[1:], exp[1:])
+    # bf16 logits and a 3-D batch go through the same entry point
+    out2 = ops.ce_topk(lg.reshape(1, N, C).bfloat16(), y.reshape(1, N), ks)
+    exp2 = ref.ce_topk(lg.bfloat16().float(), y, ks)
+    torch.testing.assert_close(out2[0], exp2[0], rtol=1e-5, atol=1e-4)
+    assert torch.equal(out2[1:], exp2[1:])
