@@ -137,6 +137,13 @@ def main():
             "phase_ms": {k: round(v, 3) for k, v in timers.items()},
             "train_loss": last.get("train_loss") if last else None,
         }
+        # BASELINE.md publishes no throughput.  For context only: tools/reference_round.py (a sequential
+        # per-client plain-PyTorch fp32 restatement of the reference round, no Ray overhead) measured
+        # 0.10715 rounds/s on one MI355X for this exact config (profiles/r1_reference_restatement_*.log).
+        if (args.model, K, f, args.aggregator, args.adversary, args.batch) == (
+                "resnet18", 1000, 200, "Median", "ALIEAdversary", 64):
+            out["reference_restatement_rounds_per_sec_1gpu"] = 0.10715
+            out["vs_reference_restatement"] = round(value / 0.10715, 2)
         print(json.dumps(out), flush=True)
     if args.torch_profile and rt.is_main:
         from torch.profiler import ProfilerActivity, profile
