@@ -384,7 +384,7 @@ def pcbn_backward(x, gy, y, gamma, mean, invstd, Kc: int, coef, U_block, off_gam
 # ---------------------------------------------------------------------------
 # per-client conv weight gradient
 _conv_wgrad = _sig("blades_conv_wgrad", [_P, _P, _P, c_long, c_long, _P, c_int] + [c_int] * 11 + [_P] + [c_int] * 5
-                   + [_P, c_int, c_int, c_long, c_int, _P], c_int)
+                   + [_P, c_int, c_int, c_int, c_long, c_int, _P], c_int)
 _wgrad_plans = {}
 
 
@@ -412,23 +412,35 @@ def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
     big = np.iinfo(np.int64).max
     glo = np.where(valid, lo_row, big).reshape(S, 8).min(axis=1)
     ghi = np.where(valid, hi_row, -1).reshape(S, 8).max(axis=1)
-    table = np.zeros((S, 36), dtype=np.int32)
+    # per step: 8 quads x 4 ints, then row_lo, row_hi, window_lo; one extra all-zero row behind the last step
+    # (the kernel's lanes that have nothing to fetch read 16 zero bytes from there)
+    table = np.zeros((S + 1, 48), dtype=np.int32)
+    # Rows a step brings in: everything it needs that is not resident yet, and — when that is less than one
+    # staging pass (32 pixels) — the next rows in sequence as well.  The look-ahead evens out the image
+    # boundaries (the last step of an image needs no new row, the first step of the next one needs two or
+    # three), so stride-1 layers never need more than one pass per step.
+    rpp = max(1, 32 // W)
+    last_row = B * H - 1
+    lo_a, hi_a = np.zeros(S, dtype=np.int64), np.zeros(S, dtype=np.int64)
     prev = -1
-    window = 1
     max_new = 0
     for s in range(S):
-        lo = max(prev + 1, int(glo[s]))
-        hi = int(ghi[s])
-        table[s, 0], table[s, 1] = lo, hi
-        table[s, 34] = int(glo[s])
-        max_new = max(max_new, (hi - lo + 1) * W)
+        lo = max(prev + 1, int(glo[s])) if s == 0 else prev + 1
+        hi = max(int(ghi[s]), min(prev + rpp, last_row))
+        lo_a[s], hi_a[s] = lo, hi
+        if s > 0:  # step 0 always starts a block: its rows come in through the synchronous window load
+            max_new = max(max_new, (hi - lo + 1) * W)
         prev = max(prev, hi)
-        nxt = int(ghi[s + 1]) if s + 1 < S else hi
+    window = 1
+    for s in range(S):
+        table[s, 32], table[s, 33] = lo_a[s], hi_a[s]
+        table[s, 34] = int(glo[s])
+        nxt = int(hi_a[s + 1]) if s + 1 < S else int(hi_a[s])
         window = max(window, nxt - int(glo[s]) + 1)
-    table[:, 2:34:4] = gy_base.reshape(S, 8)
-    table[:, 3:34:4] = gi0.reshape(S, 8)
-    table[:, 4:34:4] = ih0.reshape(S, 8)
-    table[:, 5:34:4] = ow0.reshape(S, 8)
+    table[:S, 0:32:4] = gy_base.reshape(S, 8)
+    table[:S, 1:32:4] = gi0.reshape(S, 8)
+    table[:S, 2:32:4] = ih0.reshape(S, 8)
+    table[:S, 3:32:4] = ow0.reshape(S, 8)
     nlines = 1
     while nlines < window:
         nlines *= 2
@@ -440,7 +452,7 @@ def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
     wslots = need
     while wslots % 8 != 4:
         wslots += 1
-    passes = -(-max_new // 32)
+    passes = max(1, -(-max_new // 32))
     plan = dict(table=torch.from_numpy(table).to(device), nsteps=S, nlines=nlines, wslots=wslots, passes=passes)
     _wgrad_plans[key] = plan
     return plan
@@ -507,18 +519,26 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
     n_ci_tiles = -(-Cin // 64)
     while tmt > 1 and Cout % (tmt * 16):
         tmt //= 2
-    # Too few (client, tile) blocks to fill 256 CUs (the 64-channel layers): split the pixel
-    # reduction over blocks; partial sums go through a scratch slab and are added in fixed order.
+    # 256 CUs x 2 resident blocks = 512 slots.  A grid that is not a multiple of that leaves a ragged last
+    # wave of blocks (600 blocks = one full wave + one 17 %-full wave that takes just as long), and a small
+    # grid does not fill the chip at all: split the pixel reduction over `split` blocks per tile so the grid
+    # comes out near a multiple of the slot count.  Partial sums go through a scratch slab and are added in
+    # fixed order, so the result stays deterministic.  Cost model: waves(split) / split of the full-K block
+    # time plus the slab's write + read traffic.
     blocks = Kc * (Cout // (tmt * 16)) * n_ci_tiles
-    split = 1
-    if blocks < 512:
-        split = max(1, min(8, -(-512 // blocks), plan["nsteps"] // 16))
+    slots, t_step, bw = 512, 1.5e-6, 4e12
+    best, split = None, 1
+    for sp in range(1, max(1, min(16, plan["nsteps"] // 16)) + 1):
+        waves = -(-blocks * sp // slots)
+        est = waves / sp * plan["nsteps"] * t_step + (0.0 if sp == 1 else (sp + 1) * Kc * numel * 4 / bw)
+        if best is None or est < best * 0.97:  # prefer the smaller split unless the gain is real
+            best, split = est, sp
     scratch = None
     if split > 1:
         scratch = _scratch(split * Kc * numel, x.device)
     rc = _conv_wgrad(_ptr(x), _ptr(gy), _ptr(U_block), ld, off, _ptr(coef), int(accumulate), Kc, B, H, W, Cin, Ho,
                      Wo, Cout, ks, stride, pad, _ptr(plan["table"]), plan["nsteps"], plan["nlines"], plan["wslots"],
-                     tmt, split, _ptr(scratch), rmul, cmul, x_client_stride, cin_store, _stream())
+                     tmt, split, _ptr(scratch), rmul, cmul, plan["passes"], x_client_stride, cin_store, _stream())
     if rc == 3:  # staging does not fit in LDS
         return False
     if rc != 0:

@@ -39,8 +39,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MAXP = 4;         // staging passes (32 pixels x 64 ch each) per step
-constexpr int TBL = 36;         // ints per step: row_lo,row_hi, 8 quads x {gy pixel, gi0, ih0, ow0}, window_lo, pad
+constexpr int TBL = 48;         // ints per step (192 B, 64 B-aligned rows): 8 quads x {gy pixel, gi0, ih0, ow0},
+                                // then row_lo, row_hi, window_lo at [32], [33], [34]
 
 struct WgradParams {
   const unsigned short* x;
@@ -60,6 +60,8 @@ struct WgradParams {
   long x_client_stride;  // elements between two clients' inputs
   int rmul, cmul;       // virtual pixel (row, col) -> physical pixel index row*rmul + col*cmul (1x1 strided convs
                         // are run as stride-1 on the subsampled input without copying it)
+  int ntiles, total_blocks;  // (co, ci) tiles per client; ntiles * Kc * split
+  int lg_qpr, lg_ho, nquads;  // FAST path (Wo % 4 == 0, Wo/4 and Ho powers of two): quad -> (b, oh, ow0) by shifts
   int Cs;               // input channels actually stored (< Cin when x was zero-padded to a multiple of 16)
   int ablate;           // diagnostics only: bit0 skip staging after the prologue, bit1 skip MFMA work
 };
@@ -71,18 +73,49 @@ __device__ __forceinline__ i32x2 tr_read(const unsigned char* lds_ptr) {
                                        (__attribute__((address_space(3))) s16x4*)(lds_ptr)));
 }
 
-template <int TMT, int KS>
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// 16-byte global load the compiler does not track: completion is awaited by hand with vmcnt counting (below),
+// because the compiler's own waitcnt insertion falls back to vmcnt(0) around the rotating staging registers
+// and would drain the prefetch queue every K-step.  Nothing may read the result before that manual wait.
+__device__ __forceinline__ u32x4 gload16_untracked(const void* ptr) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// MAXP: staging passes (32 pixels x 64 channels each) a K-step may need for new input rows — 1 for every
+// stride-1 layer, up to 4 for stride 2.  NPF: K-steps of global loads in flight (register-staged); the
+// stride-1 variants run 3 deep, which is what hides HBM latency (measured: staging alone cost 1.4 of 1.5 ms
+// per layer at depth 1).
+// FAST: output geometry is all powers of two (every ResNet layer), so a quad's (image, row, column) and the gy
+// pixel range of a step follow from the step index by shifts — no descriptor loads at all in the K loop; only
+// the range of new input rows still comes from the table (one 8-byte scalar load, fetched a step early).
+template <int TMT, int KS, int MAXP, int NPF, bool FAST>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int TAPS = KS * KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = blockIdx.y;
+  // 1-D grid, XCD-aware: hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so id -> id'
+  // below gives every XCD one contiguous range of logical blocks.  Logical order is tile-fastest, hence all
+  // (co, ci) tiles of one client's K-slice run on the same XCD at about the same time and share the client's
+  // x / gy rows through that XCD's L2 instead of each fetching them from HBM.
+  const int per_xcd = gridDim.x >> 3;
+  const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (lid >= p.total_blocks) return;
   const int n_ci_tiles = (p.Cin + 63) >> 6;
-  const int co0 = (blockIdx.x / n_ci_tiles) * (TMT * 16);
-  const int ci0 = (blockIdx.x % n_ci_tiles) * 64;
+  const int tile = lid % p.ntiles, rest = lid / p.ntiles;
+  const int c = rest % p.Kc, zsplit = rest / p.Kc;
+  const int co0 = (tile / n_ci_tiles) * (TMT * 16);
+  const int ci0 = (tile % n_ci_tiles) * 64;
   unsigned char* gy_lds = smem;                    // [2][TMT][32 px][16 co] bf16
   unsigned char* x_lds = smem + 2 * TMT * 1024;    // [4 ci-blocks][nlines][wslots][16 ci] bf16
-  const int plane_bytes = p.nlines * p.wslots * 32;
+  const int plane_bytes = (p.nlines + 1) * p.wslots * 32;  // ring of nlines + one all-zero line (index nlines)
   const int line_mask = p.nlines - 1;
 
   for (int i = tid * 16; i < 4 * plane_bytes; i += 256 * 16) *reinterpret_cast<u32x4*>(x_lds + i) = u32x4{0, 0, 0, 0};
@@ -94,34 +127,61 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   const int chunk = tid & 7, pix = tid >> 3;
   const bool gy_lane = chunk < TMT * 2 && (co0 + chunk * 8) < p.Cout;
   const bool x_lane = (ci0 + chunk * 8) < p.Cin;
-  u32x4 rg_gy = {0, 0, 0, 0};
-  u32x4 rg_x[MAXP];
+  struct Stg { u32x4 gy; u32x4 x[MAXP]; };
+  Stg stg[NPF];
+  // step table through the scalar cache: every index below is wave-uniform, so these loads never enter the
+  // vector-memory queue and cannot force the in-flight staging loads to drain
+  const __attribute__((address_space(4))) int* tbl =
+      (const __attribute__((address_space(4))) int*)(p.table);
+  const int wq = __builtin_amdgcn_readfirstlane(wave) * 2;  // the two gy quads this wave stages: wq, wq + 1
 
-  auto issue = [&](int s) {
-    const int* T = p.table + (size_t)s * TBL;
-    const int qd = pix >> 2, q = pix & 3;
-    const int gbase = T[2 + qd * 4 + 0], ow0 = T[2 + qd * 4 + 3];
-    rg_gy = u32x4{0, 0, 0, 0};
-    if (gy_lane && gbase >= 0 && ow0 + q < p.Wo)
-      rg_gy = *reinterpret_cast<const u32x4*>(gc + (size_t)(gbase + q) * p.Cout + co0 + chunk * 8);
-    const int row_lo = T[0], row_hi = T[1];
-    const int npix = (row_hi - row_lo + 1) * p.W;
+  // Staging pipeline.  Every issue() puts exactly 1 + MAXP loads per wave into the vector-memory queue (lanes
+  // with nothing to fetch read 16 zero bytes that sit behind the step table), so "the loads of step s+1 have
+  // landed" is the constant wait vmcnt((NPF-1) * (1 + MAXP)).  What issue() needs from the step table — the two
+  // gy quads this wave stages and the range of new input rows — is fetched through the scalar cache one
+  // iteration ahead (StepInfo) and kept in SGPRs, so neither its latency nor a vector-queue drain sits in
+  // front of the loads.
+  struct StepInfo { i32x8 q; int step, row_lo, row_hi; };
+  auto fetch_info = [&](int s) {
+    StepInfo f;
+    const __attribute__((address_space(4))) int* T = tbl + (size_t)s * TBL;
+    if constexpr (!FAST) f.q = *reinterpret_cast<const __attribute__((address_space(4))) i32x8*>(T + wq * 4);
+    f.step = s;
+    f.row_lo = T[32];
+    f.row_hi = T[33];
+    return f;
+  };
+  const unsigned short* zeros16 = reinterpret_cast<const unsigned short*>(p.table + (size_t)p.nsteps * TBL);
+  int rlo[NPF], rhi[NPF];  // new-row range of the step held by each staging slot (needed again at commit)
+  auto issue = [&](const StepInfo& f, Stg& rg) {
+    const unsigned short* ga = zeros16;
+    if constexpr (FAST) {
+      const int gpix = f.step * 32 + pix;  // quads tile the flattened pixel list: a step is 32 consecutive pixels
+      if (gy_lane && gpix < p.nquads * 4) ga = gc + (size_t)gpix * p.Cout + co0 + chunk * 8;
+    } else {
+      const bool hi_q = (lane & 32) != 0;  // pix >> 2 == wq + (lane >> 5)
+      const int gbase = hi_q ? f.q[4] : f.q[0];
+      const int ow0 = hi_q ? f.q[7] : f.q[3];
+      const int q = pix & 3;
+      if (gy_lane && gbase >= 0 && ow0 + q < p.Wo) ga = gc + (size_t)(gbase + q) * p.Cout + co0 + chunk * 8;
+    }
+    rg.gy = gload16_untracked(ga);
+    const int npix = (f.row_hi - f.row_lo + 1) * p.W;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       const int e = i * 32 + pix;
-      rg_x[i] = u32x4{0, 0, 0, 0};
+      const unsigned short* xa = zeros16;
       if (x_lane && e < npix) {
         const int er = p.w_shift >= 0 ? (e >> p.w_shift) : e / p.W;
-        const size_t pixel = (size_t)(row_lo + er) * p.rmul + (size_t)(e - er * p.W) * p.cmul;
-        rg_x[i] = *reinterpret_cast<const u32x4*>(xc + pixel * p.Cin + ci0 + chunk * 8);
+        const size_t pixel = (size_t)(f.row_lo + er) * p.rmul + (size_t)(e - er * p.W) * p.cmul;
+        xa = xc + pixel * p.Cin + ci0 + chunk * 8;
       }
+      rg.x[i] = gload16_untracked(xa);
     }
   };
-  auto commit = [&](int s) {
-    const int* T = p.table + (size_t)s * TBL;
+  auto commit = [&](int s, const Stg& rg, int row_lo, int row_hi) {
     if (chunk < TMT * 2)
-      *reinterpret_cast<u32x4*>(gy_lds + (s & 1) * TMT * 1024 + (chunk >> 1) * 1024 + pix * 32 + (chunk & 1) * 16) = rg_gy;
-    const int row_lo = T[0], row_hi = T[1];
+      *reinterpret_cast<u32x4*>(gy_lds + (s & 1) * TMT * 1024 + (chunk >> 1) * 1024 + pix * 32 + (chunk & 1) * 16) = rg.gy;
     const int npix = (row_hi - row_lo + 1) * p.W;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
@@ -131,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         const int row = row_lo + er, iw = e - er * p.W + p.pad;
         const int slot = p.stride == 1 ? iw : (iw & 1) * p.half + (iw >> 1);
         *reinterpret_cast<u32x4*>(x_lds + (chunk >> 1) * plane_bytes + ((row & line_mask) * p.wslots + slot) * 32 +
-                                  (chunk & 1) * 16) = rg_x[i];
+                                  (chunk & 1) * 16) = rg.x[i];
       }
     }
   };
@@ -148,51 +208,51 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 
   // this block's share of the K-steps
   const int per = (p.nsteps + p.split - 1) / p.split;
-  const int s_begin = blockIdx.z * per;
-  const int s_end = s_begin + per < p.nsteps ? s_begin + per : p.nsteps;
+  const int blk_begin = zsplit * per;
+  const int blk_end = blk_begin + per < p.nsteps ? blk_begin + per : p.nsteps;
+  int s_begin = 0, s_end = 0;  // the segment of [blk_begin, blk_end) being processed (see the loop at the end)
 
   __syncthreads();  // zero fill done
-  if (s_begin < s_end) {
-    // prologue: the whole row window of the first step, synchronously
-    const int* T = p.table + (size_t)s_begin * TBL;
-    const int w_lo = T[34], w_hi = T[1];
-    const int npix = (w_hi - w_lo + 1) * p.W;
-    for (int e = pix; e < npix; e += 32) {
-      if (x_lane) {
-        const int er = p.w_shift >= 0 ? (e >> p.w_shift) : e / p.W;
-        const size_t pixel = (size_t)(w_lo + er) * p.rmul + (size_t)(e - er * p.W) * p.cmul;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(xc + pixel * p.Cin + ci0 + chunk * 8);
-        const int row = w_lo + er, iw = e - er * p.W + p.pad;
-        const int slot = p.stride == 1 ? iw : (iw & 1) * p.half + (iw >> 1);
-        *reinterpret_cast<u32x4*>(x_lds + (chunk >> 1) * plane_bytes + ((row & line_mask) * p.wslots + slot) * 32 +
-                                  (chunk & 1) * 16) = v;
-      }
-    }
-    {  // gy tile of the first step
-      const int qd = pix >> 2, q = pix & 3;
-      const int gbase = T[2 + qd * 4 + 0], ow0 = T[2 + qd * 4 + 3];
-      u32x4 v = {0, 0, 0, 0};
-      if (gy_lane && gbase >= 0 && ow0 + q < p.Wo)
-        v = *reinterpret_cast<const u32x4*>(gc + (size_t)(gbase + q) * p.Cout + co0 + chunk * 8);
-      if (chunk < TMT * 2)
-        *reinterpret_cast<u32x4*>(gy_lds + (s_begin & 1) * TMT * 1024 + (chunk >> 1) * 1024 + pix * 32 +
-                                  (chunk & 1) * 16) = v;
-    }
-  }
   // quad descriptors of the two reads of a K-step, prefetched one step ahead
   int d_gb[2], d_gi[2], d_ih[2], d_ow[2];
   auto load_desc = [&](int s) {
-    const int* T = p.table + (size_t)s * TBL;
+    if constexpr (FAST) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int* Q = T + 2 + (4 * t + g) * 4;
-      d_gb[t] = Q[0]; d_gi[t] = Q[1]; d_ih[t] = Q[2]; d_ow[t] = Q[3];
+      for (int t = 0; t < 2; ++t) {
+        const int Q = s * 8 + 4 * t + g;
+        const int qx = Q & ((1 << p.lg_qpr) - 1);
+        const int oh = (Q >> p.lg_qpr) & ((1 << p.lg_ho) - 1);
+        const int b = Q >> (p.lg_qpr + p.lg_ho);
+        d_gb[t] = Q < p.nquads ? 0 : -1;
+        d_ow[t] = qx * 4;
+        d_ih[t] = oh * p.stride - p.pad;
+        d_gi[t] = b * p.H + d_ih[t];
+      }
+      return;
     }
+    // all eight quads through two 64-byte scalar loads, then each 16-lane group picks its own (g, g + 4)
+    const __attribute__((address_space(4))) i32x16* T16 =
+        reinterpret_cast<const __attribute__((address_space(4))) i32x16*>(tbl + (size_t)s * TBL);
+    const i32x16 qa = T16[0], qb = T16[1];
+    int v[2][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      int x = qa[f], y = qb[f];
+      x = g == 1 ? qa[4 + f] : x;  y = g == 1 ? qb[4 + f] : y;
+      x = g == 2 ? qa[8 + f] : x;  y = g == 2 ? qb[8 + f] : y;
+      x = g == 3 ? qa[12 + f] : x; y = g == 3 ? qb[12 + f] : y;
+      v[0][f] = x; v[1][f] = y;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { d_gb[t] = v[t][0]; d_gi[t] = v[t][1]; d_ih[t] = v[t][2]; d_ow[t] = v[t][3]; }
   };
-  if (s_begin < s_end) load_desc(s_begin);
-  __syncthreads();
 
-  for (int s = s_begin; s < s_end; ++s) {
+  int tapoff[KS];  // byte offset of kernel column sx inside a line (parity-split slots for stride 2)
+#pragma unroll
+  for (int sx = 0; sx < KS; ++sx) tapoff[sx] = (p.stride == 1 ? sx : (sx & 1) * p.half + (sx >> 1)) * 32;
+
+  StepInfo nxt;  // table info of the next step to be issued (s + NPF), fetched one iteration early
+  auto step = [&](int s, Stg& slot_far, int& far_lo, int& far_hi, const Stg& slot_next, const int& next_lo, const int& next_hi) {
     int gi0[2], ih0[2], ow0[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -200,11 +260,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
       ih0[t] = d_gb[t] >= 0 ? d_ih[t] : -1000000;  // quads past the end: every row invalid
       ow0[t] = d_ow[t];
     }
-    const bool stage = (s + 1 < s_end) && !(p.ablate & 1);
+    const bool ablate_stage = (p.ablate & 1) != 0;
+    if (s + NPF < s_end && !ablate_stage) {
+      issue(nxt, slot_far);  // into the slot step s no longer needs
+      far_lo = nxt.row_lo;
+      far_hi = nxt.row_hi;
+    }
+    if (s + NPF + 1 < s_end) nxt = fetch_info(s + NPF + 1);  // scalar loads; consumed next iteration
     if (s + 1 < s_end) load_desc(s + 1);
-    if (stage) issue(s + 1);
     if (wave_active && !(p.ablate & 2)) {
       const unsigned char* gy_buf = gy_lds + (s & 1) * TMT * 1024 + lq * 32 + lp * 8;
+      // Row base pointers of the two quads this lane reads (t = 0, 1).  Input rows outside the image (and
+      // quads past the end of the pixel list) point at the all-zero line, so fragments need no masking.
+      const unsigned char* bp[KS][2];
+#pragma unroll
+      for (int r = 0; r < KS; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ih = ih0[t] + r;
+          const int line = ((unsigned)ih < (unsigned)p.H) ? ((gi0[t] + r) & line_mask) : p.nlines;
+          bp[r][t] = x_plane + (line * p.wslots + ow0[t]) * 32;
+        }
+      // B fragments are fetched one kernel row ahead of the MFMAs that use them; the A fragments and row 0
+      // go first.  sched_barriers keep the compiler from sinking the reads back down to their uses.
+      i32x2 hb[2][KS * 2];
+#pragma unroll
+      for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) hb[0][sx * 2 + t] = tr_read(bp[0][t] + tapoff[sx]);
       i32x4 a[TMT];
 #pragma unroll
       for (int m = 0; m < TMT; ++m) {
@@ -214,39 +297,96 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
       }
 #pragma unroll
       for (int r = 0; r < KS; ++r) {
-        int line_off[2];
-        int msk[2];
+        if (r + 1 < KS) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int ih = ih0[t] + r;
-          msk[t] = (ih >= 0 && ih < p.H) ? -1 : 0;
-          line_off[t] = ((gi0[t] + r) & line_mask) * p.wslots;
+          for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) hb[(r + 1) & 1][sx * 2 + t] = tr_read(bp[r + 1][t] + tapoff[sx]);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sx = 0; sx < KS; ++sx) {
-          i32x2 h[2];
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const int slot = p.stride == 1 ? ow0[t] + sx : (sx & 1) * p.half + ow0[t] + (sx >> 1);
-            h[t] = tr_read(x_plane + (line_off[t] + slot) * 32) & i32x2{msk[t], msk[t]};
-          }
-          const i32x4 b = {h[0][0], h[0][1], h[1][0], h[1][1]};
+          const i32x2 h0 = hb[r & 1][sx * 2 + 0], h1 = hb[r & 1][sx * 2 + 1];
+          const i32x4 b = {h0[0], h0[1], h1[0], h1[1]};
 #pragma unroll
           for (int m = 0; m < TMT; ++m)
             acc[m][r * KS + sx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 __builtin_bit_cast(bf16x8, a[m]), __builtin_bit_cast(bf16x8, b), acc[m][r * KS + sx], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (stage) commit(s + 1);
+    if (s + 1 < s_end && !ablate_stage) {
+      // loads newer than step s+1's: NPF-1 steps' worth while the queue is full, fewer (so wait for all) at the tail
+      if (s + NPF < s_end) wait_vmcnt<(NPF - 1) * (1 + MAXP)>();
+      else wait_vmcnt<0>();
+      commit(s + 1, slot_next, next_lo, next_hi);
+    }
     __syncthreads();
+  };
+  // Every client's x / gy block is a power-of-two number of bytes, so blocks that walk their K range in
+  // lockstep from the same relative offset hit the same HBM channels at the same time (measured: ~2 TB/s no
+  // matter how deep the prefetch).  Each block therefore starts at its own rotation point of its step range
+  // and wraps around: segment 0 = [blk_begin + rot, blk_end), segment 1 = [blk_begin, blk_begin + rot).
+  const int nblk_steps = blk_end - blk_begin;
+  const int rot = (nblk_steps > 1 && !(p.ablate & 4)) ? (int)(((unsigned)c * 7919u + (unsigned)zsplit * 104729u) % (unsigned)nblk_steps) : 0;
+  for (int seg = 0; seg < 2; ++seg) {
+    s_begin = seg == 0 ? blk_begin + rot : blk_begin;
+    s_end = seg == 0 ? blk_end : blk_begin + rot;
+    if (s_begin >= s_end) continue;
+    {
+      // prologue: the whole row window of the first step, synchronously
+      const __attribute__((address_space(4))) int* T = tbl + (size_t)s_begin * TBL;
+      const int w_lo = T[34], w_hi = T[33];
+      const int npix = (w_hi - w_lo + 1) * p.W;
+      for (int e = pix; e < npix; e += 32) {
+        if (x_lane) {
+          const int er = p.w_shift >= 0 ? (e >> p.w_shift) : e / p.W;
+          const size_t pixel = (size_t)(w_lo + er) * p.rmul + (size_t)(e - er * p.W) * p.cmul;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(xc + pixel * p.Cin + ci0 + chunk * 8);
+          const int row = w_lo + er, iw = e - er * p.W + p.pad;
+          const int slot = p.stride == 1 ? iw : (iw & 1) * p.half + (iw >> 1);
+          *reinterpret_cast<u32x4*>(x_lds + (chunk >> 1) * plane_bytes + ((row & line_mask) * p.wslots + slot) * 32 +
+                                    (chunk & 1) * 16) = v;
+        }
+      }
+      {  // gy tile of the first step
+        const int qd = pix >> 2, q = pix & 3;
+        const int gbase = T[qd * 4 + 0], ow0 = T[qd * 4 + 3];
+        u32x4 v = {0, 0, 0, 0};
+        if (gy_lane && gbase >= 0 && ow0 + q < p.Wo)
+          v = *reinterpret_cast<const u32x4*>(gc + (size_t)(gbase + q) * p.Cout + co0 + chunk * 8);
+        if (chunk < TMT * 2)
+          *reinterpret_cast<u32x4*>(gy_lds + (s_begin & 1) * TMT * 1024 + (chunk >> 1) * 1024 + pix * 32 +
+                                    (chunk & 1) * 16) = v;
+      }
+    }
+    load_desc(s_begin);
+    __syncthreads();
+    // steps already in flight when the loop starts: s_begin + 1 .. s_begin + NPF - 1
+  #pragma unroll
+    for (int k = 1; k < NPF; ++k)
+      if (s_begin + k < s_end && !(p.ablate & 1)) {
+        const StepInfo f = fetch_info(s_begin + k);
+        issue(f, stg[k]);
+        rlo[k] = f.row_lo;
+        rhi[k] = f.row_hi;
+      }
+    if (s_begin + NPF < s_end) nxt = fetch_info(s_begin + NPF);
+    // slot of step s is (s - s_begin) % NPF; the loop is unrolled NPF-fold so every slot index is static
+    for (int s0 = s_begin; s0 < s_end; s0 += NPF) {
+  #pragma unroll
+      for (int k = 0; k < NPF; ++k)
+        if (s0 + k < s_end)
+          step(s0 + k, stg[k], rlo[k], rhi[k], stg[(k + 1) % NPF], rlo[(k + 1) % NPF], rhi[(k + 1) % NPF]);
+    }
   }
 
   // ---- epilogue: D rows = co (lane>>4)*4+reg, cols = ci (lane&15) ------------------------------
   if (wave_active) {
     const bool to_scratch = p.split > 1;
     const float cf = (p.coef && !to_scratch) ? p.coef[c] : 1.f;
-    float* row = to_scratch ? p.scratch + ((size_t)blockIdx.z * p.Kc + c) * p.numel : p.U + (size_t)c * p.ld + p.off;
+    float* row = to_scratch ? p.scratch + ((size_t)zsplit * p.Kc + c) * p.numel : p.U + (size_t)c * p.ld + p.off;
     const bool accum = p.accumulate && !to_scratch;
     const int ci = ci0 + wave * 16 + li;
 #pragma unroll
@@ -279,18 +419,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-template <int TMT, int KS>
+template <int TMT, int KS, int MAXP, int NPF, bool FAST>
 int launch(const WgradParams& p, int Kc, hipStream_t st) {
-  const size_t lds = 2 * TMT * 1024 + 4 * (size_t)p.nlines * p.wslots * 32;
+  const size_t lds = 2 * TMT * 1024 + 4 * (size_t)(p.nlines + 1) * p.wslots * 32;
   if (lds > 160 * 1024) return 3;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TMT, KS>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int n_ci_tiles = (p.Cin + 63) / 64, n_co_tiles = p.Cout / (TMT * 16);
-  hipLaunchKernelGGL((conv_wgrad_kernel<TMT, KS>), dim3(n_co_tiles * n_ci_tiles, Kc, p.split), dim3(256), lds, st, p);
+  WgradParams q = p;
+  q.ntiles = n_co_tiles * n_ci_tiles;
+  q.total_blocks = q.ntiles * Kc * p.split;
+  const int grid = (q.total_blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL((conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST>), dim3(grid), dim3(256), lds, st, q);
   if (p.split > 1) {
     int gx = cdiv(p.numel, 256 * 4);
     if (gx > 1024) gx = 1024;
@@ -306,7 +450,7 @@ int launch(const WgradParams& p, int Kc, hipStream_t st) {
 BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long ld, long off, const float* coef,
                                  int accumulate, int Kc, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
                                  int ks, int stride, int pad, const int* table, int nsteps, int nlines, int wslots,
-                                 int tmt, int split, float* scratch, int rmul, int cmul,
+                                 int tmt, int split, float* scratch, int rmul, int cmul, int passes,
                                  long x_client_stride, int cin_store, hipStream_t st) {
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || Cin % 16 || Cout % 16) return 1;
   if (nlines & (nlines - 1)) return 2;
@@ -324,7 +468,18 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
   if (p.split > 1 && scratch == nullptr) return 6;
   { const char* e = getenv("BLADES_WGRAD_ABLATE"); p.ablate = e ? atoi(e) : 0; }
   if (Cout % (tmt * 16)) return 4;
-#define GO(T, K) return launch<T, K>(p, Kc, st)
+  // power-of-two output geometry -> descriptor-free K loop
+  const int qpr = (Wo + 3) / 4;
+  const bool fast = (Wo % 4 == 0) && !(qpr & (qpr - 1)) && !(Ho & (Ho - 1));
+  p.lg_qpr = p.lg_ho = 0;
+  while ((1 << p.lg_qpr) < qpr) ++p.lg_qpr;
+  while ((1 << p.lg_ho) < Ho) ++p.lg_ho;
+  p.nquads = B * Ho * qpr;
+#define GO(T, K)                                                                        \
+  do {                                                                                  \
+    if (fast) return passes <= 1 ? launch<T, K, 1, 3, true>(p, Kc, st) : launch<T, K, 4, 1, true>(p, Kc, st); \
+    return passes <= 1 ? launch<T, K, 1, 2, false>(p, Kc, st) : launch<T, K, 4, 1, false>(p, Kc, st);           \
+  } while (0)
   if (ks == 3) { if (tmt == 4) GO(4, 3); if (tmt == 2) GO(2, 3); if (tmt == 1) GO(1, 3); }
   else { if (tmt == 4) GO(4, 1); if (tmt == 2) GO(2, 1); if (tmt == 1) GO(1, 1); }
 #undef GO
