@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=200, help="clients vectorised per kernel chunk")
     ap.add_argument("--amp", default="bf16")
     ap.add_argument("--samples-per-client", type=int, default=128)
+    ap.add_argument("--local-steps", type=int, default=1, help="client SGD steps per round (1 = FedSGD headline)")
     ap.add_argument("--cpu", action="store_true", help="debug: run on CPU/gloo")
     ap.add_argument("--torch-profile", default=None,
                     help="after the timed rounds, run one more under torch.profiler and write the op table here")
@@ -73,7 +74,7 @@ def main():
                                  "use_cache": False})
            .training(global_model=args.model,
                      server_config={"aggregator": agg, "optimizer": {"lr": 0.1, "momentum": 0.0}})
-           .client(client_config={"lr": 1.0, "momentum": 0.0, "num_batch_per_round": 1})
+           .client(client_config={"lr": 1.0, "momentum": 0.0, "num_batch_per_round": args.local_steps})
            .adversary(num_malicious_clients=f,
                       adversary_config={"type": f"blades.adversaries.{args.adversary}"})
            .evaluation(evaluation_interval=0)
@@ -129,7 +130,7 @@ def main():
             "config": {
                 "model": args.model, "dataset": "cifar10", "num_clients": K, "num_malicious": f,
                 "adversary": args.adversary, "aggregator": args.aggregator, "client_batch": args.batch,
-                "global_batch": (K - f) * args.batch, "local_steps": 1, "update_dim": algo.engine.D,
+                "global_batch": (K - f) * args.batch, "local_steps": args.local_steps, "update_dim": algo.engine.D,
                 "parallelism": f"clients sharded over {world} GPU(s); all-to-all to D-sharded aggregation",
             },
             "client_updates_per_sec": round(value * (K - f), 2),
@@ -140,8 +141,8 @@ def main():
         # BASELINE.md publishes no throughput.  For context only: tools/reference_round.py (a sequential
         # per-client plain-PyTorch fp32 restatement of the reference round, no Ray overhead) measured
         # 0.10715 rounds/s on one MI355X for this exact config (profiles/r1_reference_restatement_*.log).
-        if (args.model, K, f, args.aggregator, args.adversary, args.batch) == (
-                "resnet18", 1000, 200, "Median", "ALIEAdversary", 64):
+        if (args.model, K, f, args.aggregator, args.adversary, args.batch, args.local_steps) == (
+                "resnet18", 1000, 200, "Median", "ALIEAdversary", 64, 1):
             out["reference_restatement_rounds_per_sec_1gpu"] = 0.10715
             out["vs_reference_restatement"] = round(value / 0.10715, 2)
         print(json.dumps(out), flush=True)

@@ -384,7 +384,7 @@ def pcbn_backward(x, gy, y, gamma, mean, invstd, Kc: int, coef, U_block, off_gam
 # ---------------------------------------------------------------------------
 # per-client conv weight gradient
 _conv_wgrad = _sig("blades_conv_wgrad", [_P, _P, _P, c_long, c_long, _P, c_int] + [c_int] * 11 + [_P] + [c_int] * 5
-                   + [_P, c_int, c_int, c_int, c_long, c_int, _P], c_int)
+                   + [_P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, _P], c_int)
 _wgrad_plans = {}
 
 
@@ -453,7 +453,19 @@ def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
     while wslots % 8 != 4:
         wslots += 1
     passes = max(1, -(-max_new // 32))
-    plan = dict(table=torch.from_numpy(table).to(device), nsteps=S, nlines=nlines, wslots=wslots, passes=passes)
+    # Is the new-row range arithmetic?  hi[s] = min((s+1)*R + off, last), lo[s] = min(s*R + off, last) + 1 for s > 0.
+    rows_r, rows_off = 0, 0
+    if S > 1:
+        R = int(hi_a[1] - hi_a[0]) if S > 1 else 0
+        off = int(hi_a[0]) - R
+        if R > 0:
+            sidx = np.arange(S)
+            hi_f = np.minimum((sidx + 1) * R + off, last_row)
+            lo_f = np.minimum(sidx * R + off, last_row) + 1
+            if np.array_equal(hi_f[1:], hi_a[1:]) and np.array_equal(lo_f[1:], lo_a[1:]):
+                rows_r, rows_off = R, off
+    plan = dict(table=torch.from_numpy(table).to(device), nsteps=S, nlines=nlines, wslots=wslots, passes=passes,
+                rows_r=rows_r, rows_off=rows_off)
     _wgrad_plans[key] = plan
     return plan
 
@@ -538,7 +550,7 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
         scratch = _scratch(split * Kc * numel, x.device)
     rc = _conv_wgrad(_ptr(x), _ptr(gy), _ptr(U_block), ld, off, _ptr(coef), int(accumulate), Kc, B, H, W, Cin, Ho,
                      Wo, Cout, ks, stride, pad, _ptr(plan["table"]), plan["nsteps"], plan["nlines"], plan["wslots"],
-                     tmt, split, _ptr(scratch), rmul, cmul, plan["passes"], x_client_stride, cin_store, _stream())
+                     tmt, split, _ptr(scratch), rmul, cmul, plan["passes"], plan["rows_r"], plan["rows_off"], x_client_stride, cin_store, _stream())
     if rc == 3:  # staging does not fit in LDS
         return False
     if rc != 0:

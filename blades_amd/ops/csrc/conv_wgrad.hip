@@ -61,6 +61,7 @@ struct WgradParams {
   int rmul, cmul;       // virtual pixel (row, col) -> physical pixel index row*rmul + col*cmul (1x1 strided convs
                         // are run as stride-1 on the subsampled input without copying it)
   int ntiles, total_blocks;  // (co, ci) tiles per client; ntiles * Kc * split
+  int rows_r, rows_off, rows_last;  // rows_r > 0: new-row range of step s is arithmetic (see fetch_info)
   int lg_qpr, lg_ho, nquads;  // FAST path (Wo % 4 == 0, Wo/4 and Ho powers of two): quad -> (b, oh, ow0) by shifts
   int Cs;               // input channels actually stored (< Cin when x was zero-padded to a multiple of 16)
   int ablate;           // diagnostics only: bit0 skip staging after the prologue, bit1 skip MFMA work
@@ -144,9 +145,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   struct StepInfo { i32x8 q; int step, row_lo, row_hi; };
   auto fetch_info = [&](int s) {
     StepInfo f;
+    f.step = s;
+    if (FAST && p.rows_r > 0) {
+      // regular geometry (checked on the host against the planned table): step s > 0 brings in the rows
+      // (s*R + off, (s+1)*R + off], clipped to the client's last row — nothing to load at all
+      const int hi = (s + 1) * p.rows_r + p.rows_off, lo = s * p.rows_r + p.rows_off;
+      f.row_hi = hi < p.rows_last ? hi : p.rows_last;
+      f.row_lo = (lo < p.rows_last ? lo : p.rows_last) + 1;
+      return f;
+    }
     const __attribute__((address_space(4))) int* T = tbl + (size_t)s * TBL;
     if constexpr (!FAST) f.q = *reinterpret_cast<const __attribute__((address_space(4))) i32x8*>(T + wq * 4);
-    f.step = s;
     f.row_lo = T[32];
     f.row_hi = T[33];
     return f;
@@ -450,7 +459,7 @@ int launch(const WgradParams& p, int Kc, hipStream_t st) {
 BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long ld, long off, const float* coef,
                                  int accumulate, int Kc, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
                                  int ks, int stride, int pad, const int* table, int nsteps, int nlines, int wslots,
-                                 int tmt, int split, float* scratch, int rmul, int cmul, int passes,
+                                 int tmt, int split, float* scratch, int rmul, int cmul, int passes, int rows_r, int rows_off,
                                  long x_client_stride, int cin_store, hipStream_t st) {
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || Cin % 16 || Cout % 16) return 1;
   if (nlines & (nlines - 1)) return 2;
@@ -475,6 +484,7 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
   while ((1 << p.lg_qpr) < qpr) ++p.lg_qpr;
   while ((1 << p.lg_ho) < Ho) ++p.lg_ho;
   p.nquads = B * Ho * qpr;
+  p.rows_r = rows_r; p.rows_off = rows_off; p.rows_last = B * H - 1;
 #define GO(T, K)                                                                        \
   do {                                                                                  \
     if (fast) return passes <= 1 ? launch<T, K, 1, 3, true>(p, Kc, st) : launch<T, K, 4, 1, true>(p, Kc, st); \
