@@ -120,6 +120,33 @@ class ClientEngine:
         self.fused = None
         if self.mode in ("auto", "batched", "fused") and fused.supports(task.model):
             self.fused = fused.FusedFedSGD(task, self.names, self.offsets, self.numels, self.amp_dtype, self.device)
+        # several local steps: per-client weights -> grouped wide-network executor, if the model passes its
+        # layout self-check (otherwise the torch.vmap path)
+        self.grouped = None
+        if self.nb > 1 and self.mode in ("auto", "batched", "fused") and self.Kloc > 0:
+            from . import grouped
+
+            if grouped.supports(task.model):
+                ge = grouped.GroupedLocalSGD(task, self.names, self.shapes, self.offsets[:-1], self.numels,
+                                             self.amp_dtype, self.device)
+
+                def ref(W, X, Y):
+                    was = self.model.training
+                    self.model.eval()
+                    try:
+                        amp, self.amp_dtype = self.amp_dtype, None
+                        g, _ = self._grads(self._params_from_flat(W, batched=True), X, Y, per_client_params=True)
+                        self.amp_dtype = amp
+                        R = torch.empty_like(W)
+                        self._flatten_into(g, R)
+                        return R
+                    finally:
+                        self.model.train(was)
+
+                ncls = int(getattr(dataset, "num_classes", 10) or 10)
+                if ge.self_check(ref, self.D, tuple(self.train_store.x.shape[1:]), ncls):
+                    self.grouped = ge
+                self.grouped_check = getattr(ge, "check_error", None)  # diagnostics: error or exception text
 
     # ------------------------------------------------------------------
     def refresh_client_specs(self):
@@ -259,9 +286,12 @@ class ClientEngine:
         loss_acc = torch.zeros(Kc, device=self.device)
         for step in range(self.nb):
             X, Y = self._fetch_batch(srows, flip)
-            grads, losses = self._grads(self._params_from_flat(W, batched=True), X, Y, per_client_params=True)
-            self._flatten_into(grads, G)
-            del grads
+            if self.grouped is not None:
+                losses = self.grouped.run(W, X, Y, G)
+            else:
+                grads, losses = self._grads(self._params_from_flat(W, batched=True), X, Y, per_client_params=True)
+                self._flatten_into(grads, G)
+                del grads
             gs = gscale0
             if bool(torch.isfinite(gclip).any()):
                 gs = gs * self._clip_coef(ops.row_sqnorm(G), gclip)

@@ -64,3 +64,31 @@ def test_fused_signflip_labelflip_clip_momentum(data_root):
         Ub, _ = one_round_updates(b)
         torch.testing.assert_close(Ua, Ub, rtol=2e-3, atol=2e-5)
     assert float(Ua.norm(dim=1).max()) <= 0.5 * 0.05 * 1.9 + 1e-4  # lr * clip * (1 + momentum)
+
+
+@pytest.mark.parametrize("model,expect_grouped", [("resnet", True), ("mlp", False), ("cnn", False)])
+def test_grouped_local_steps_equal_vectorised(data_root, model, expect_grouped):
+    """Several local steps: the grouped wide-network executor (client-innermost layout, grouped conv + plain
+    BatchNorm) must reproduce the torch.vmap path; a model whose forward is not layout-agnostic (the CNN's
+    `unsqueeze(1)`) fails the self-check and stays on vmap."""
+    ds = "cifar10" if model == "resnet" else "fashionmnist"
+    a = build(data_root, model, "fused", ds, nb=3, momentum=0.9, lr=0.02)
+    b = build(data_root, model, "vmap", ds, nb=3, momentum=0.9, lr=0.02)
+    assert (a.engine.grouped is not None) == expect_grouped, getattr(a.engine, 'grouped_check', None)
+    assert b.engine.grouped is None
+    if not expect_grouped:
+        return
+    for algo in (a, b):
+        for net in (algo.engine.task.model, algo.engine.model, algo.engine.grouped.template if algo.engine.grouped else None):
+            if net is not None:
+                net.apply(lambda m: setattr(m, "p", 0.0) if isinstance(m, torch.nn.modules.dropout._DropoutNd) else None)
+    # The two paths round differently (one wide grouped kernel vs per-client kernels) and a ReLU sitting on zero
+    # can flip: per-step gradients agree to ~1e-6 with occasional 1e-3 outliers, which training at random init
+    # amplifies round over round.  So: direction and size per client, tight in round 1, loose in round 2.
+    for rnd, (tol_rel, tol_cos) in enumerate([(5e-3, 0.9999), (1e-1, 0.99)]):
+        Ua, ta = one_round_updates(a)
+        Ub, tb = one_round_updates(b)
+        cos = torch.nn.functional.cosine_similarity(Ua, Ub, dim=1)
+        rel = (Ua - Ub).norm(dim=1) / Ub.norm(dim=1)
+        assert float(cos.min()) > tol_cos, (rnd, cos)
+        assert float(rel.max()) < tol_rel, (rnd, rel)
