@@ -98,6 +98,7 @@ def main():
         sync()
         note(f"warmup round {i} (includes MIOpen kernel search): {time.perf_counter() - tw:.1f}s")
     sync()
+    algo._timers.reset()  # phase means below cover the timed rounds only
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):

@@ -51,6 +51,14 @@ class PhaseTimers:
                 keep.append((name, a, b))
         self._pending = keep
 
+    def reset(self):
+        """Forget everything measured so far (e.g. warm-up rounds)."""
+        if self.gpu:
+            self._resolve(True)
+        self.totals.clear()
+        self.counts.clear()
+        self.last.clear()
+
     def snapshot(self, block: bool = False) -> dict:
         """Last completed duration of every phase, in ms."""
         if self.gpu:
