@@ -321,3 +321,77 @@ def test_ce_topk(dev, N, C):
     exp2 = ref.ce_topk(lg.bfloat16().float(), y, ks)
     torch.testing.assert_close(out2[0], exp2[0], rtol=1e-5, atol=1e-4)
     assert torch.equal(out2[1:], exp2[1:])
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("Mean", {}), ("Median", {}), ("Trimmedmean", {"num_byzantine": 4}), ("GeoMed", {}),
+    ("DnC", {"num_byzantine": 4, "sub_dim": 500}), ("Multikrum", {"num_byzantine": 4, "k": 3}),
+    ("Centeredclipping", {}), ("Clippedclustering", {}), ("Clippedclustering", {"signguard": True, "agg": "median"}),
+    ("Signguard", {}), ("Signguard", {"agg": "median"})])
+def test_aggregators_gpu_match_cpu(dev, name, kw):
+    """Every aggregator end to end: HIP kernels on the GPU vs the PyTorch oracle ops on the CPU, two rounds
+    (the stateful ones carry their state over)."""
+    from blades_amd import aggregators as A
+    from blades_amd.parallel.context import local_context
+
+    K, D = 21, 3001
+    g = torch.Generator().manual_seed(7)
+    a_cpu, a_gpu = getattr(A, name)(**kw), getattr(A, name)(**kw)
+    ctx = local_context(D)
+    for rnd in range(2):
+        U = torch.randn(K, D, generator=g) * 0.1
+        U[:4] += 0.5 * (rnd + 1)  # a shifted cluster for the filters to find
+        out_c = a_cpu.aggregate(U.clone(), ctx)
+        out_g = a_gpu.aggregate(U.clone().to(dev), ctx)
+        assert out_g.is_cuda
+        torch.testing.assert_close(out_g.cpu(), out_c, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("cls_name,kw,agg", [
+    ("ALIEAdversary", {}, None), ("ALIEAdversary", {}, "Signguard"), ("IPMAdversary", {"scale": 0.1}, None),
+    ("IPMAdversary", {"scale": 100.0}, None), ("NoiseAdversary", {}, None), ("AdaptiveAdversary", {}, None),
+    ("MinMaxAdversary", {}, None), ("MinMaxAdversary", {}, "Signguard"), ("SignGuardAdversary", {}, None),
+    ("AttackclippedclusteringAdversary", {}, None)])
+def test_update_forging_adversaries_gpu_match_cpu(dev, cls_name, kw, agg):
+    """Every update-forging adversary: rows forged by the HIP kernels on the GPU vs the oracle ops on the CPU
+    (same counter-based random streams on both devices)."""
+    from unittest.mock import MagicMock
+
+    from blades_amd import adversaries as ADV, aggregators as A
+    from blades_amd.parallel.context import local_context
+
+    K, f, D = 16, 4, 2050
+    gcfg = MagicMock()
+    gcfg.num_clients, gcfg.seed = K, 7
+
+    def algo_for(U):
+        algo = MagicMock()
+        algo.update_matrix = U
+        mask = torch.ones(K, device=U.device)
+        mask[:f] = 0
+        algo.benign_mask = mask
+        algo.malicious_rows = torch.arange(f, device=U.device)
+        algo.malicious_row_clients = torch.arange(f)
+        algo.row_clients = torch.arange(K)
+        algo.ctx = local_context(D)
+        algo.server.aggregator = getattr(A, agg)() if agg else A.Mean()
+        algo.local_results = []
+        return algo
+
+    g = torch.Generator().manual_seed(3)
+    outs = []
+    for device in ("cpu", dev):
+        adv = getattr(ADV, cls_name)([object()] * f, gcfg, **kw)
+        gg = torch.Generator().manual_seed(3)
+        res = []
+        for rnd in range(2):
+            U = torch.randn(K, D, generator=gg) * 0.1 + 0.02
+            U[:f] = 0
+            U = U.to(device)
+            adv.on_local_round_end(algo_for(U))
+            res.append(U.cpu())
+        outs.append(res)
+    for uc, ug in zip(*outs):
+        assert torch.equal(uc[f:], ug[f:])  # benign rows untouched on both
+        scale = float(uc[:f].abs().max())
+        torch.testing.assert_close(ug[:f], uc[:f], rtol=2e-3, atol=2e-4 * max(1.0, scale))
