@@ -31,7 +31,8 @@ class Aggregator:
             U = torch.stack([t.reshape(-1) for t in inputs], dim=0)
         if U.dtype != torch.float32:
             U = U.float()
-        U = U.contiguous()
+        if U.dim() != 2 or U.stride(1) != 1:  # a row-strided view of a padded buffer is fine as it is
+            U = U.contiguous()
         if ctx is None:
             ctx = local_context(U.shape[1])
         return self.aggregate(U, ctx)

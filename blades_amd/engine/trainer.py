@@ -110,7 +110,12 @@ class ClientEngine:
         self.test_store = dataset.device_store(ids, self.device, "test")
 
         # ---- persistent buffers
-        self.U_row = torch.zeros(self.Kloc, self.Dpad, dtype=torch.float32, device=self.device)
+        # Row stride is always a multiple of COL_ALIGN floats, also on one GPU where the logical width is the
+        # unpadded D: rows that start float4-aligned are what the streaming kernels' vector paths need
+        # (Mean over 1000 x 11.2 M: 7.5 ms with aligned rows, 31 ms without).
+        ld = padded_width(self.Dpad, 1)
+        self._U_store = torch.zeros(self.Kloc, ld, dtype=torch.float32, device=self.device)
+        self.U_row = self._U_store[:, : self.Dpad]
         self.U_col = self.U_row if G == 1 else torch.zeros(self.K, self.Dl, dtype=torch.float32,
                                                             device=self.device)
         self.M = None  # per-client momentum buffers [Kloc_train, D], lazily

@@ -170,3 +170,26 @@ def test_host_clustering_large_k_matches_sklearn():
         a = host.agglomerative2(d, linkage)
         b = AgglomerativeClustering(metric="precomputed", linkage=linkage, n_clusters=2).fit(d).labels_
         assert (a == b).all() or (a == 1 - b).all(), linkage
+
+
+def test_geomed_gram_formulation_matches_direct():
+    """Weiszfeld in coefficient space (one Gram pass + O(K^2) iterations) gives the direct form's result."""
+    from blades_amd.aggregators import GeoMed
+    from blades_amd.parallel.context import local_context
+
+    g = torch.Generator().manual_seed(5)
+    U = torch.randn(40, 3000, generator=g) * 0.1
+    U[:8] += 0.7
+    ctx = local_context(3000)
+    a = GeoMed(method="direct").aggregate(U, ctx)
+    gm = GeoMed(method="gram")
+    b = gm.aggregate(U, ctx)
+    assert gm.last_info["method"] == "gram"
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+    w = torch.rand(40, generator=g) + 0.1
+    torch.testing.assert_close(GeoMed(method="direct").aggregate(U, ctx, w), GeoMed(method="gram").aggregate(U, ctx, w),
+                               rtol=1e-4, atol=1e-6)
+    # a row sitting exactly on the median (distance 0 -> eps clamp) behaves the same in both forms
+    V = torch.cat([U[:5], U[:5].mean(0, keepdim=True)])
+    torch.testing.assert_close(GeoMed(method="direct").aggregate(V, ctx), GeoMed(method="gram").aggregate(V, ctx),
+                               rtol=1e-3, atol=1e-5)

@@ -324,7 +324,7 @@ def test_ce_topk(dev, N, C):
 
 
 @pytest.mark.parametrize("name,kw", [
-    ("Mean", {}), ("Median", {}), ("Trimmedmean", {"num_byzantine": 4}), ("GeoMed", {}),
+    ("Mean", {}), ("Median", {}), ("Trimmedmean", {"num_byzantine": 4}), ("GeoMed", {}), ("GeoMed", {"method": "gram"}),
     ("DnC", {"num_byzantine": 4, "sub_dim": 500}), ("Multikrum", {"num_byzantine": 4, "k": 3}),
     ("Centeredclipping", {}), ("Clippedclustering", {}), ("Clippedclustering", {"signguard": True, "agg": "median"}),
     ("Signguard", {}), ("Signguard", {"agg": "median"})])
