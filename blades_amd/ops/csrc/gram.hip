@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict_
 
   constexpr int F4_PER_TILE = B * (BK / 4);      // float4 per operand tile
   constexpr int LOADS = F4_PER_TILE / 256;        // per thread per operand
-  for (long c0 = c_begin; c0 < c_end; c0 += BK) {
-    f32x4 ra[LOADS], rb[LOADS];
+  // Global loads run one K-step ahead of the MFMAs: the tile of step c0 + BK is fetched into registers while
+  // the tile of step c0 (already in LDS) is being multiplied, so HBM latency hides behind ~4000 MFMA cycles.
+  f32x4 ra[LOADS], rb[LOADS];
+  auto fetch = [&](long c0) {
 #pragma unroll
     for (int q = 0; q < LOADS; ++q) {
       const int f = q * 256 + tid;
@@ -79,6 +81,9 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict_
       }
       ra[q] = va; rb[q] = vb;
     }
+  };
+  if (c_begin < c_end) fetch(c_begin);
+  for (long c0 = c_begin; c0 < c_end; c0 += BK) {
     __syncthreads();  // previous step's reads done
 #pragma unroll
     for (int q = 0; q < LOADS; ++q) {
@@ -88,6 +93,7 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict_
       *reinterpret_cast<f32x4*>(Bs + row * LDS_LD + k4) = rb[q];
     }
     __syncthreads();
+    if (c0 + BK < c_end) fetch(c0 + BK);
 #pragma unroll
     for (int t = 0; t < BK / 8; ++t) {
       f32x4 fa[T], fb[T];
