@@ -92,12 +92,29 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     note(f"setup done: K={K} f={f} D={algo.engine.D} world={world}")
+    # MIOpen's kernel search makes the first round take a minute or two without any output of its own:
+    # a heartbeat on stderr keeps log-silence watchdogs from mistaking that for a hang
+    import threading
+
+    warming = threading.Event()
+    warming.set()
+
+    def heartbeat():
+        t_start = time.perf_counter()
+        while warming.is_set():
+            time.sleep(20)
+            if warming.is_set():
+                note(f"warming up ... {time.perf_counter() - t_start:.0f}s")
+
+    hb = threading.Thread(target=heartbeat, daemon=True)
+    hb.start()
     for i in range(args.warmup):
         tw = time.perf_counter()
         algo.train()
         sync()
         note(f"warmup round {i} (includes MIOpen kernel search): {time.perf_counter() - tw:.1f}s")
     sync()
+    warming.clear()
     algo._timers.reset()  # phase means below cover the timed rounds only
     t0 = time.perf_counter()
     last = None
