@@ -143,6 +143,17 @@ class Server(LearningRateSchedule):
             dist.all_gather_into_tensor(self.theta, sl.clone(), group=self.ctx.group)
 
     # -- checkpoint ---------------------------------------------------------
+    def _aggregator_state(self) -> dict:
+        """Aggregator state with column-sharded vectors (Centeredclipping's momentum) gathered to full width, so
+        a checkpoint written by rank 0 holds every rank's slice and can be resumed at any world size."""
+        st = self._aggregator.state_dict() if hasattr(self._aggregator, "state_dict") else {}
+        mom = getattr(self._aggregator, "momentum", None)
+        if "momentum" in st and isinstance(mom, Tensor):
+            full = self.ctx.all_gather_cols(mom) if self.ctx.distributed else mom
+            st = dict(st)
+            st["momentum"] = full[: self.D].detach().cpu()
+        return st
+
     def state_dict(self) -> dict:
         return {
             "theta": self.theta[: self.D].detach().cpu(),
@@ -150,7 +161,7 @@ class Server(LearningRateSchedule):
                 self.momentum_buf).detach().cpu(),
             "cur_lr": self.cur_lr,
             "steps": self._steps,
-            "aggregator": self._aggregator.state_dict() if hasattr(self._aggregator, "state_dict") else {},
+            "aggregator": self._aggregator_state(),
         }
 
     def load_state_dict(self, s: dict) -> None:
@@ -164,6 +175,12 @@ class Server(LearningRateSchedule):
         self._steps = s["steps"]
         if hasattr(self._aggregator, "load_state_dict"):
             st = s.get("aggregator", {})
-            if "momentum" in st and st["momentum"] is not None and self.ctx.distributed:
-                st = dict(st)  # Centeredclipping momentum is stored full-width
+            if isinstance(st.get("momentum", None), Tensor):
+                # stored full-width: take this rank's column slice (zero-padded up to the shard width)
+                full = torch.zeros(self.Dl * self.ctx.world_size, device=self.theta.device)
+                m = st["momentum"].to(self.theta.device)
+                full[: m.numel()] = m
+                lo = self.ctx.col_offset
+                st = dict(st)
+                st["momentum"] = full[lo: lo + self.Dl].clone()
             self._aggregator.load_state_dict(st)

@@ -61,3 +61,24 @@ def test_multi_batch_general_path_two_ranks(tmp_path):
     ref = run(1, spec, str(tmp_path / "a.pt"))
     got = run(2, spec, str(tmp_path / "b.pt"))
     torch.testing.assert_close(got["theta"], ref["theta"], rtol=1e-3, atol=1e-4)
+
+
+def test_checkpoint_gathers_column_sharded_aggregator_state(tmp_path):
+    """Centeredclipping's momentum lives column-sharded across ranks; a checkpoint written by rank 0 of a
+    2-rank job must hold the full vector — the one a single-process run ends up with."""
+    import pickle
+
+    spec = {"K": 8, "f": 2, "agg": {"type": "Centeredclipping"},
+            "adv": {"type": "blades.adversaries.IPMAdversary", "scale": 0.1}, "rounds": 2, "root": str(tmp_path)}
+    states = {}
+    for world in (1, 2):
+        ck = tmp_path / f"ckpt_w{world}"
+        ck.mkdir()
+        run(world, dict(spec, ckpt=str(ck)), str(tmp_path / f"c{world}.pt"))
+        with open(ck / "algorithm_state.pkl", "rb") as fh:
+            states[world] = pickle.load(fh)  # written by this test's own workers
+    m1 = states[1]["server"]["aggregator"]["momentum"]
+    m2 = states[2]["server"]["aggregator"]["momentum"]
+    assert m1.shape == m2.shape and m1.numel() == 136074  # full MLP width, not one rank's shard
+    torch.testing.assert_close(m2, m1, rtol=1e-3, atol=1e-5)
+    assert "config" in states[2]
