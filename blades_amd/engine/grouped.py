@@ -149,8 +149,12 @@ class GroupedLocalSGD:
             t = W[:, o: o + n].detach().reshape(Kc, *s).clone().requires_grad_(True)
             setattr(slot, leaf, t)
             leaves.append(t)
-        x = X.transpose(0, 1)  # [B, Kc, ...]
-        x = x.reshape(B, Kc * x.shape[2], *x.shape[3:]) if x.dim() > 2 else x.reshape(B, Kc)
+        x = X.transpose(0, 1)  # [B, Kc, *sample]
+        if x.dim() == 5 or x.dim() == 3:  # images with a channel axis / flat features: clients fold into it
+            x = x.reshape(B, Kc * x.shape[2], *x.shape[3:])
+        elif x.dim() == 2:
+            x = x.reshape(B, Kc)
+        # channel-less images [B, Kc, H, W] already read as "Kc single-channel images side by side"
         if self.amp_dtype is not None:
             x = x.to(self.amp_dtype)
         if x.dim() == 4 and x.is_cuda:

@@ -17,7 +17,7 @@ class MLP(nn.Module):
         self.dropout = nn.Dropout(p_drop)
 
     def forward(self, x):
-        x = x.reshape(-1, self.in_features)
+        x = x.reshape(x.shape[0], -1)  # one row per sample (also lets a grouped executor fold clients into the row)
         x = self.dropout(F.relu(self.fc1(x)))
         x = self.dropout(F.relu(self.fc2(x)))
         return self.fc3(x)

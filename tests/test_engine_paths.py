@@ -66,11 +66,10 @@ def test_fused_signflip_labelflip_clip_momentum(data_root):
     assert float(Ua.norm(dim=1).max()) <= 0.5 * 0.05 * 1.9 + 1e-4  # lr * clip * (1 + momentum)
 
 
-@pytest.mark.parametrize("model,expect_grouped", [("resnet", True), ("mlp", False), ("cnn", False)])
+@pytest.mark.parametrize("model,expect_grouped", [("resnet", True), ("mlp", True), ("cnn", True)])
 def test_grouped_local_steps_equal_vectorised(data_root, model, expect_grouped):
     """Several local steps: the grouped wide-network executor (client-innermost layout, grouped conv + plain
-    BatchNorm) must reproduce the torch.vmap path; a model whose forward is not layout-agnostic (the CNN's
-    `unsqueeze(1)`) fails the self-check and stays on vmap."""
+    BatchNorm) must reproduce the torch.vmap path for every catalogue CNN/MLP/ResNet."""
     ds = "cifar10" if model == "resnet" else "fashionmnist"
     a = build(data_root, model, "fused", ds, nb=3, momentum=0.9, lr=0.02)
     b = build(data_root, model, "vmap", ds, nb=3, momentum=0.9, lr=0.02)
