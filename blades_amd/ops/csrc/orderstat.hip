@@ -27,8 +27,8 @@
 //     cover 128 contiguous bytes of every row at L = 8); blockIdx is remapped
 //     so that neighbouring column groups run on the same XCD and share L2 lines.
 //
-// `fill` (optional, N floats) marks dead rows: 0 = live row, otherwise the pad
-// value to sort instead of the row's data.  The host side builds it from the
+// `fill` (optional, N + 1 floats) marks dead rows: 0 = live row, otherwise the pad
+// value to sort instead of the row's data; slot N carries the live-row count.  The host side builds it from the
 // row mask; without a mask only rows >= K are padded and that is done inline.
 #include "common.h"
 
