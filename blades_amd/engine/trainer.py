@@ -22,6 +22,8 @@ vectorisation the statistics are per (client, channel), as they must be.
 Afterwards the row shard ``[K_r, Dpad]`` is re-laid-out into the column shard
 ``[K, Dl]`` with one RCCL all-to-all (identity when ``world_size == 1``).
 """
+import contextlib
+import os
 import time
 from typing import Dict, List, Optional, Tuple
 
@@ -118,6 +120,8 @@ class ClientEngine:
         self.U_row = self._U_store[:, : self.Dpad]
         self.U_col = self.U_row if G == 1 else torch.zeros(self.K, self.Dl, dtype=torch.float32,
                                                             device=self.device)
+        self.n_streams = max(1, int(os.environ.get("BLADES_CHUNK_STREAMS", "1")))
+        self._streams = None
         self.M = None  # per-client momentum buffers [Kloc_train, D], lazily
         self._mom_init = False
         from . import fused
@@ -343,20 +347,33 @@ class ClientEngine:
         # with any of those the exchange cannot start early
         late = bool(seq) or self._has_round_end_hooks()
         self._exchange_begin()
+        # Optional: chunks alternate between `n_streams` HIP streams so that one chunk's memory-bound kernels
+        # (per-client BN, elementwise) can overlap another chunk's MFMA-bound convolutions.
+        n_streams = self.n_streams if (dev.type == "cuda" and not late) else 1
+        streams = self._chunk_streams(n_streams)
+        pending = []
         with torch.enable_grad():
-            for c0 in range(0, len(batched), self.chunk):
+            for ci, c0 in enumerate(range(0, len(batched), self.chunk)):
                 ks = np.array(batched[c0: c0 + self.chunk], dtype=np.int64)
                 rows = self._train_rows[ks]
-                if self.nb == 1:
-                    losses = self._train_chunk_fedsgd(theta, rows, ks)
-                else:
-                    losses = self._train_chunk_general(theta, rows, ks)
-                benign = torch.tensor([not self._malicious[r] for r in rows], device=dev)
-                loss_sum += (losses.double() * benign).sum()
-                loss_cnt += benign.sum()
-                if not late and c0 + self.chunk < len(batched):
+                st = streams[ci % len(streams)] if streams else None
+                if st is not None:
+                    st.wait_stream(torch.cuda.current_stream())
+                with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                    if self.nb == 1:
+                        losses = self._train_chunk_fedsgd(theta, rows, ks)
+                    else:
+                        losses = self._train_chunk_general(theta, rows, ks)
+                    benign = torch.tensor([not self._malicious[r] for r in rows], device=dev)
+                    pending.append(((losses.double() * benign).sum(), benign.sum()))
+                if st is None and not late and c0 + self.chunk < len(batched):
                     # everything below the next untrained row is final: ship it while the next chunk trains
                     self._exchange_upto(int(self._train_rows[batched[c0 + self.chunk]]))
+        for st in streams or []:
+            torch.cuda.current_stream().wait_stream(st)
+        for ls, cnt in pending:
+            loss_sum += ls
+            loss_cnt += cnt
         for k in seq:
             r = int(self._train_rows[k])
             l = self._train_sequential(theta, r)
@@ -376,6 +393,13 @@ class ClientEngine:
         self.timers["exchange_s"] = time.perf_counter() - t1
         self.round += 1
         return U, loss_sum, loss_cnt
+
+    def _chunk_streams(self, n: int):
+        if n <= 1:
+            return None
+        if self._streams is None or len(self._streams) != n:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        return self._streams
 
     def _round_end_rows(self):
         return [r for r in self._train_rows if self._specs[r] and (

@@ -474,8 +474,9 @@ _scratch_buf = {}
 
 
 def _scratch(n: int, device) -> torch.Tensor:
-    """Grow-only fp32 workspace per device (stream-ordered reuse: all users run on the current stream)."""
-    key = str(device)
+    """Grow-only fp32 workspace per (device, stream): reuse is stream-ordered, so chunks that run on different
+    streams must not share a slab."""
+    key = (str(device), int(torch.cuda.current_stream().cuda_stream))
     buf = _scratch_buf.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(int(n * 1.25) + 1024, device=device, dtype=torch.float32)

@@ -203,6 +203,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
       }
       rg.x[i] = gload16_untracked(xa);
     }
+    // The table-driven variants are register-tight enough for the compiler to spill; a spill of a staging
+    // register before its load has landed would save garbage, so they wait here (they are the slow general
+    // path anyway).  The FAST variants must compile without spills — tools/check_wgrad_spills.py verifies it.
+    if constexpr (!FAST) wait_vmcnt<0>();
   };
   auto commit = [&](int s, const Stg& rg, int row_lo, int row_hi) {
     if (chunk < TMT * 2)
@@ -408,11 +412,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   }
 
   // ---- epilogue: D rows = co (lane>>4)*4+reg, cols = ci (lane&15) ------------------------------
+  const bool to_scratch = p.split > 1;
+  const float cf = (p.coef && !to_scratch) ? p.coef[c] : 1.f;
+  float* row = to_scratch ? p.scratch + ((size_t)zsplit * p.Kc + c) * p.numel : p.U + (size_t)c * p.ld + p.off;
+  const bool accum = p.accumulate && !to_scratch;
+  if (p.ablate & 8) return;
+  // For a fixed output channel a wave's 16 input channels x TAPS form one contiguous run of the weight
+  // tensor (16*TAPS floats), but in registers a lane holds TAPS floats of it — writing from there means 4-byte
+  // stores 36 bytes apart.  For 3x3 kernels the tile goes through LDS instead (the staging buffers are free
+  // now) and comes back out lane-contiguous: every store instruction covers 256 consecutive bytes.  Measured
+  // on the 512-channel layers: epilogue 0.8 -> ~0.35 ms of a 1.8 ms kernel.
+  constexpr int SEG = 16 * TAPS, SEGP = SEG + 4;
+  const bool full_tile = (p.Cs == p.Cin) && (ci0 + 64 <= p.Cin);  // block-uniform
+  if (TAPS > 1 && full_tile) {
+    float* tile = reinterpret_cast<float*>(smem) + wave * 16 * SEGP;  // [16 co rows][SEGP] per wave
+#pragma unroll
+    for (int m = 0; m < TMT; ++m) {
+      __syncthreads();  // previous pass read out / K loop done with the staging buffers
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) tile[(g * 4 + q) * SEGP + li * TAPS + t] = cf * acc[m][t][q];
+      __syncthreads();
+      float* dst0 = row + ((size_t)(co0 + m * 16) * p.Cin + ci0 + wave * 16) * TAPS;
+#pragma unroll
+      for (int j = 0; j < 16 * SEG / 64; ++j) {
+        const int f = j * 64 + lane;
+        const int r = f / SEG, col = f - r * SEG;
+        float* d = dst0 + (size_t)r * p.Cin * TAPS + col;
+        const float v = tile[r * SEGP + col];
+        *d = accum ? *d + v : v;
+      }
+    }
+    return;
+  }
   if (wave_active) {
-    const bool to_scratch = p.split > 1;
-    const float cf = (p.coef && !to_scratch) ? p.coef[c] : 1.f;
-    float* row = to_scratch ? p.scratch + ((size_t)zsplit * p.Kc + c) * p.numel : p.U + (size_t)c * p.ld + p.off;
-    const bool accum = p.accumulate && !to_scratch;
     const int ci = ci0 + wave * 16 + li;
 #pragma unroll
     for (int m = 0; m < TMT; ++m)
@@ -446,7 +480,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 template <int TMT, int KS, int MAXP, int NPF, bool FAST>
 int launch(const WgradParams& p, int Kc, hipStream_t st) {
-  const size_t lds = 2 * TMT * 1024 + 4 * (size_t)(p.nlines + 1) * p.wslots * 32;
+  size_t lds = 2 * TMT * 1024 + 4 * (size_t)(p.nlines + 1) * p.wslots * 32;
+  const size_t lds_epilogue = 4 * 16 * (16 * KS * KS + 4) * sizeof(float);  // LDS-transposed write-out
+  if (KS > 1 && lds < lds_epilogue) lds = lds_epilogue;
   if (lds > 160 * 1024) return 3;
   static bool attr = false;
   if (!attr) {
