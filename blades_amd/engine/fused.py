@@ -225,11 +225,14 @@ class _PCBatchNormFn(torch.autograd.Function):
         Kc = sink.Kc
         use_hip = x.is_cuda and _hipmod().pcbn_supported(x) and (res is None or _hipmod().pcbn_supported(res))
         if use_hip:
-            y, mean, invstd = _hipmod().pcbn_forward(x, res, mod.weight, mod.bias, Kc, mod.eps, relu)
+            # the kernel leaves the ReLU gate as a bitmask (1/16 of y's bytes) for the backward pass
+            y, mean, invstd, gate = _hipmod().pcbn_forward(x, res, mod.weight, mod.bias, Kc, mod.eps, relu,
+                                                           want_mask=True)
         else:
             y, mean, invstd = _bn_forward_ref(x, res, mod.weight, mod.bias, Kc, mod.eps, relu)
+            gate = y if relu else None
         ctx.mod, ctx.relu, ctx.has_res, ctx.use_hip = mod, relu, res is not None, use_hip
-        ctx.save_for_backward(x, y if relu else None, mean, invstd)
+        ctx.save_for_backward(x, gate, mean, invstd)
         return y
 
     @staticmethod

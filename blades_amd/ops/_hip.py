@@ -56,8 +56,8 @@ _augment = _sig("blades_augment_batch", [_P, _P, _P, c_int, c_int, c_int, c_int,
 
 
 _pcbn_nchunk = _sig("blades_pcbn_nchunk", [c_int, c_int], c_int)
-_pcbn_fwd = _sig("blades_pcbn_forward", [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, _P],
-                 c_int)
+_pcbn_fwd = _sig("blades_pcbn_forward", [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
+                                         _P], c_int)
 _pcbn_bwd = _sig("blades_pcbn_backward", [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_long, c_long, c_long,
                                           c_int, _P, _P, _P, _P, _P, _P, _P], c_int)
 
@@ -322,7 +322,7 @@ def pcbn_supported(x: torch.Tensor) -> bool:
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool):
+def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask: bool = False):
     _chk_nhwc_bf16(x, "x")
     N, C, H, W = x.shape
     if N % Kc != 0:
@@ -339,23 +339,28 @@ def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool):
     partial = torch.empty(Kc * nch * C * 2, device=dev)
     stats = torch.empty(4, Kc, C, device=dev)
     y = torch.empty_like(x)
+    # ReLU gate for the backward pass: 1 bit per element (8 channels of a pixel = 1 byte) instead of y itself
+    mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (relu and want_mask) else None
     rc = _pcbn_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), Kc, P, C, eps, int(relu), _ptr(partial),
-                   _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(y), _stream())
+                   _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(y), _ptr(mask), _stream())
     if rc != 0:
         raise ValueError("pcbn_forward: unsupported shape")
+    if want_mask:
+        return y, stats[0], stats[1], mask
     return y, stats[0], stats[1]
 
 
-def pcbn_backward(x, gy, y, gamma, mean, invstd, Kc: int, coef, U_block, off_gamma: int, off_beta: int,
+def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block, off_gamma: int, off_beta: int,
                   accumulate: bool, want_gres: bool):
+    """``relu_mask``: the uint8 bitmask returned by ``pcbn_forward(..., want_mask=True)`` (``None`` = no ReLU)."""
     _chk_nhwc_bf16(x, "x")
     _chk_nhwc_bf16(gy, "gy")
     if gy.shape != x.shape:
         raise ValueError("gy shape mismatch")
-    if y is not None:
-        _chk_nhwc_bf16(y, "y")
-        if y.shape != x.shape:
-            raise ValueError("y shape mismatch")
+    if relu_mask is not None:
+        if not (relu_mask.is_cuda and relu_mask.dtype == torch.uint8 and relu_mask.is_contiguous()
+                and relu_mask.numel() * 8 == x.numel()):
+            raise ValueError("relu_mask must be the contiguous uint8 bitmask of pcbn_forward (numel = x.numel() / 8)")
     N, C, H, W = x.shape
     P = (N // Kc) * H * W
     dev = x.device
@@ -373,7 +378,7 @@ def pcbn_backward(x, gy, y, gamma, mean, invstd, Kc: int, coef, U_block, off_gam
     k = torch.empty(3, Kc, C, device=dev)
     dx = torch.empty_like(x)
     gres = torch.empty_like(x) if want_gres else None
-    rc = _pcbn_bwd(_ptr(x), _ptr(gy), _ptr(y), _ptr(gamma), _ptr(mean), _ptr(invstd), Kc, P, C, _ptr(coef),
+    rc = _pcbn_bwd(_ptr(x), _ptr(gy), _ptr(relu_mask), _ptr(gamma), _ptr(mean), _ptr(invstd), Kc, P, C, _ptr(coef),
                    _ptr(U_block), ld, off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(k[0]), _ptr(k[1]),
                    _ptr(k[2]), _ptr(dx), _ptr(gres), _stream())
     if rc != 0:

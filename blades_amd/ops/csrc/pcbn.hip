@@ -28,11 +28,11 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 
 // partial[(c * nchunk + chunk) * C * 2 + ch * 2 + {0,1}]
-// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g * xhat), g = gy * mask(y>0 if y)
+// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g * xhat), g = gy gated by the ReLU bitmask (if any)
 template <int MODE>
 __global__ __launch_bounds__(TPB) void pcbn_reduce_kernel(const unsigned short* __restrict__ x,
                                                           const unsigned short* __restrict__ gy,
-                                                          const unsigned short* __restrict__ y,
+                                                          const unsigned char* __restrict__ mask,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int P, int C,
                                                           int pix_per_chunk, int nchunk,
@@ -61,12 +61,12 @@ __global__ __launch_bounds__(TPB) void pcbn_reduce_kernel(const unsigned short* 
       for (int j = 0; j < 8; ++j) { const float v = bf2f(xv[j]); a[j] += v; b[j] += v * v; }
     } else {
       const u16x8 gv = *reinterpret_cast<const u16x8*>(gy + off);
-      u16x8 yv = gv;
-      if (y != nullptr) yv = *reinterpret_cast<const u16x8*>(y + off);
+      // one mask byte per lane: bit j = (output j of this lane's 8 channels was > 0 in the forward pass)
+      const unsigned mb = mask != nullptr ? mask[off >> 3] : 0xFFu;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float g = bf2f(gv[j]);
-        if (y != nullptr && !(bf2f(yv[j]) > 0.f)) g = 0.f;
+        if (!((mb >> j) & 1u)) g = 0.f;
         a[j] += g;
         b[j] += g * (bf2f(xv[j]) - mu[j]) * is[j];
       }
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const unsigned shor
                                                              const unsigned short* __restrict__ res,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int P, int C, int relu,
-                                                             unsigned short* __restrict__ y) {
+                                                             unsigned short* __restrict__ y,
+                                                             unsigned char* __restrict__ mask) {
   const int client = blockIdx.y;
   const int lpp = C >> 3;
   const size_t nvec = (size_t)P * lpp;
@@ -129,14 +130,18 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const unsigned shor
     u16x8 rv = xv;
     if (res != nullptr) rv = *reinterpret_cast<const u16x8*>(res + off);
     u16x8 out;
+    unsigned mb = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float val = bf2f(xv[j]) * sc[j] + sh[j];
       if (res != nullptr) val += bf2f(rv[j]);
       if (relu) val = fmaxf(val, 0.f);
       out[j] = f2bf(val);
+      mb |= (bf2f(out[j]) > 0.f ? 1u : 0u) << j;  // gate on the rounded value the next layer actually sees
     }
     *reinterpret_cast<u16x8*>(y + off) = out;
+    // ReLU gate for the backward pass, 1 bit per element instead of re-reading y (2 bytes per element)
+    if (mask != nullptr) mask[off >> 3] = (unsigned char)mb;
   }
 }
 
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_kernel(const float* __r
 
 __global__ __launch_bounds__(TPB) void pcbn_bwd_apply_kernel(const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ gy,
-                                                             const unsigned short* __restrict__ y,
+                                                             const unsigned char* __restrict__ mask,
                                                              const float* __restrict__ k_a,
                                                              const float* __restrict__ k_bx,
                                                              const float* __restrict__ k_cc, int P, int C,
@@ -196,13 +201,12 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_apply_kernel(const unsigned shor
     const size_t off = base + v * 8;
     const u16x8 xv = *reinterpret_cast<const u16x8*>(x + off);
     const u16x8 gv = *reinterpret_cast<const u16x8*>(gy + off);
-    u16x8 yv = gv;
-    if (y != nullptr) yv = *reinterpret_cast<const u16x8*>(y + off);
+    const unsigned mb = mask != nullptr ? mask[off >> 3] : 0xFFu;
     u16x8 o, r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float g = bf2f(gv[j]);
-      if (y != nullptr && !(bf2f(yv[j]) > 0.f)) g = 0.f;
+      if (!((mb >> j) & 1u)) g = 0.f;
       o[j] = f2bf(ka[j] * g + kb[j] * bf2f(xv[j]) + kc[j]);
       r[j] = f2bf(g);
     }
@@ -224,7 +228,7 @@ BLADES_API int blades_pcbn_nchunk(int P, int C) { return cdiv(P, chunk_pixels(C)
 // workspace `partial`: Kc * nchunk * C * 2 floats.
 BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* gamma, const float* beta, int Kc,
                                    int P, int C, float eps, int relu, float* partial, float* mean, float* invstd,
-                                   float* scale, float* shift, void* y, hipStream_t st) {
+                                   float* scale, float* shift, void* y, void* relu_mask, hipStream_t st) {
   if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
   const int ppc = chunk_pixels(C), nch = cdiv(P, ppc);
   hipLaunchKernelGGL((pcbn_reduce_kernel<0>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st,
@@ -234,26 +238,28 @@ BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* 
   int gx = cdiv((long)P * (C / 8), TPB);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL(pcbn_fwd_apply_kernel, dim3(gx, Kc), dim3(TPB), 0, st, (const unsigned short*)x,
-                     (const unsigned short*)res, scale, shift, P, C, relu, (unsigned short*)y);
+                     (const unsigned short*)res, scale, shift, P, C, relu, (unsigned short*)y,
+                     (unsigned char*)relu_mask);
   return 0;
 }
 
 // workspace: partial (as forward), k_scale/k_b/k_c: Kc*C floats each.
-BLADES_API int blades_pcbn_backward(const void* x, const void* gy, const void* y, const float* gamma,
+// relu_mask: the bitmask written by the forward pass (Kc*P*C/8 bytes), or nullptr when there was no ReLU.
+BLADES_API int blades_pcbn_backward(const void* x, const void* gy, const void* relu_mask, const float* gamma,
                                     const float* mean, const float* invstd, int Kc, int P, int C, const float* coef,
                                     float* U, long ld, long off_gamma, long off_beta, int accumulate, float* partial,
                                     float* k_scale, float* k_b, float* k_c, void* dx, void* gres, hipStream_t st) {
   if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
   const int ppc = chunk_pixels(C), nch = cdiv(P, ppc);
   hipLaunchKernelGGL((pcbn_reduce_kernel<1>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st,
-                     (const unsigned short*)x, (const unsigned short*)gy, (const unsigned short*)y, mean, invstd, P, C,
-                     ppc, nch, partial);
+                     (const unsigned short*)x, (const unsigned short*)gy, (const unsigned char*)relu_mask, mean, invstd,
+                     P, C, ppc, nch, partial);
   hipLaunchKernelGGL(pcbn_bwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
                      gamma, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c);
   int gx = cdiv((long)P * (C / 8), TPB);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL(pcbn_bwd_apply_kernel, dim3(gx, Kc), dim3(TPB), 0, st, (const unsigned short*)x,
-                     (const unsigned short*)gy, (const unsigned short*)y, k_scale, k_b, k_c, P, C,
+                     (const unsigned short*)gy, (const unsigned char*)relu_mask, k_scale, k_b, k_c, P, C,
                      (unsigned short*)dx, (unsigned short*)gres);
   return 0;
 }

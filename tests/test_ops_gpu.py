@@ -212,15 +212,22 @@ def test_pcbn_kernels(dev, Kc, B, C, H, relu, res):
     x, r, gy = mk(), (mk() if res else None), mk()
     gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
     beta = torch.randn(C, generator=g).to(dev)
-    y, mean, invstd = h.pcbn_forward(x, r, gamma, beta, Kc, 1e-5, relu)
+    y, mean, invstd, gate = h.pcbn_forward(x, r, gamma, beta, Kc, 1e-5, relu, want_mask=True)
     y2, mean2, invstd2 = fused._bn_forward_ref(x, r, gamma, beta, Kc, 1e-5, relu)
+    assert (gate is None) == (not relu)
+    if relu:  # bit j of byte i = (element 8*i + j of the channels-last output is positive)
+        bits = ((gate.unsqueeze(1) >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(-1).bool()
+        assert torch.equal(bits, (y.permute(0, 2, 3, 1).reshape(-1) > 0))
+        # backward below gates with the oracle's y: build the oracle's bitmask the same way
+        pos = (y2.permute(0, 2, 3, 1).reshape(-1, 8) > 0).to(torch.uint8)
+        gate = (pos << torch.arange(8, device=dev, dtype=torch.uint8)).sum(1).to(torch.uint8)
     torch.testing.assert_close(mean, mean2, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(invstd, invstd2, rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(y.float(), y2.float(), rtol=2e-2, atol=2e-2)
     D = 3 * C + 7
     U = torch.zeros(Kc, D, device=dev)
     coef = torch.tensor([(-1.0) ** i * (i + 1) for i in range(Kc)], device=dev)
-    dx, gres = h.pcbn_backward(x, gy, y2 if relu else None, gamma, mean2, invstd2, Kc, coef, U, 5, C + 6, False,
+    dx, gres = h.pcbn_backward(x, gy, gate if relu else None, gamma, mean2, invstd2, Kc, coef, U, 5, C + 6, False,
                                res and relu)
     dx2, gres2, dgamma, dbeta = fused._bn_backward_ref(x, gy, y2, gamma, mean2, invstd2, Kc, relu, res and relu)
     torch.testing.assert_close(dx.float(), dx2.float(), rtol=3e-2, atol=3e-2)
