@@ -37,6 +37,10 @@ class WorkerGroup:
         self._scaling = scaling
         self._worker = Worker(worker_spec.task_spec, scaling, device=device)
         self._is_local = True
+        from .actor_manager import ActorManager
+
+        self._manager = ActorManager(self._worker, max_remote_requests_in_flight_per_actor=
+                                     max_remote_requests_in_flight_per_actor)
 
     @property
     def workers(self) -> list:
@@ -68,7 +72,9 @@ class WorkerGroup:
         return out
 
     def execute_with_actor_pool(self, func: Callable, values: Sequence, affinity_actors=None) -> List:
-        return self.local_execute(func, values)
+        """Collective over the ranks of the job (``parallel/actor_manager.py``): each value runs on one rank of its
+        affinity list and every rank receives all results in submission order.  Single process: a plain loop."""
+        return self._manager.execute_with_actor_pool(func, values, affinity_actors)
 
     def local_execute(self, func: Callable, values: Sequence) -> List:
         return [self._worker.apply(func, v) for v in values]

@@ -67,3 +67,19 @@ def get_device(num_gpus: float = 0, index: int = 0) -> torch.device:
     if num_gpus > 0 and torch.cuda.is_available():
         return torch.device("cuda", index)
     return torch.device("cpu")
+
+
+def apply_grad_clipping(optimizer: torch.optim.Optimizer, grad_clip: Optional[float] = None) -> dict:
+    """Clip the global gradient norm of every param group to ``grad_clip`` (reference
+    ``fllib/utils/torch_utils.py`` keeps RLlib's helper of this name).  Returns ``{"grad_gnorm": …}``."""
+    if grad_clip is None:
+        return {}
+    total = 0.0
+    clipped = False
+    for group in optimizer.param_groups:
+        params = [p for p in group["params"] if p.grad is not None]
+        if params:
+            n = torch.nn.utils.clip_grad_norm_(params, grad_clip)
+            total += float(n)
+            clipped = True
+    return {"grad_gnorm": total} if clipped else {}

@@ -30,7 +30,8 @@ def main():
     algo = cfg.build()
     # no dropout: torch's per-rank RNG is the one source of randomness that is not keyed by client
     for m in [algo.engine.model, algo.server.get_global_model()] + (
-            [algo.engine.fused.template] if algo.engine.fused is not None else []):
+            [algo.engine.fused.template] if algo.engine.fused is not None else []) + (
+            [algo.engine.grouped.template] if getattr(algo.engine, "grouped", None) is not None else []):
         for mod in m.modules():
             if isinstance(mod, torch.nn.modules.dropout._DropoutNd):
                 mod.p = 0.0

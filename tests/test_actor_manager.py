@@ -1,0 +1,144 @@
+"""Rank task farm, tensor queue, result reduction (reference: fllib/core/execution/actor_manager.py,
+fllib/utils/queue.py, fllib/core/execution/reduce_result_dict_fn.py)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from blades_amd.parallel.actor_manager import ActorManager, _ActorPool, assign_to_ranks
+from blades_amd.parallel.reduce_result_dict_fn import _reduce_mean_results, _reduce_weighted_mean_results
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _W:
+    def __init__(self, name="w"):
+        self.name = name
+
+    def apply(self, func, *args):
+        return func(self, *args)
+
+
+def test_assignment_balances_and_respects_affinity():
+    assert assign_to_ranks(6, 3) == [0, 1, 2, 0, 1, 2]
+    owner = assign_to_ranks(5, 3, [[2], [2], None, [1, 2], [0, 1]])
+    assert owner[:2] == [2, 2] and owner[2] == 0 and owner[3] == 1 and owner[4] == 0
+    with pytest.raises(ValueError):
+        assign_to_ranks(2, 2, [[0]])
+    with pytest.raises(ValueError):
+        assign_to_ranks(1, 2, [[5]])
+    # cost-weighted: one heavy value keeps its rank free of the light ones
+    assert assign_to_ranks(4, 2, cost=[10, 1, 1, 1]) == [0, 1, 1, 1]
+
+
+def test_pool_is_ordered_and_honours_affinity():
+    a, b = _W("a"), _W("b")
+    pool = _ActorPool([a, b])
+    pool.submit(lambda w, v: (w.name, v), 1)
+    pool.submit(lambda w, v: (w.name, v), 2, affinity_actors=[b])
+    pool.submit(lambda w, v: (w.name, v), 3)
+    out = []
+    while pool.has_next():
+        out.append(pool.get_next())
+    assert out == [("a", 1), ("b", 2), ("b", 3)]
+    assert list(pool.map(lambda w, v: v * 2, [1, 2, 3])) == [2, 4, 6]
+    with pytest.raises(ValueError):
+        pool.submit(lambda w, v: v, 1, affinity_actors=[_W("stranger")])
+
+
+def test_manager_single_process():
+    m = ActorManager(_W())
+    assert m.execute_with_actor_pool(lambda w, v: v + 1, [1, 2, 3]) == [2, 3, 4]
+    assert m.foreach_actor(lambda w: w.name) == ["w"]
+    with pytest.raises(ZeroDivisionError):
+        m.execute_with_actor_pool(lambda w, v: 1 // v, [1, 0])
+
+
+def test_manager_across_ranks(tmp_path):
+    script = tmp_path / "farm.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, json
+        import torch.distributed as dist
+        sys.path.insert(0, %r)
+        from blades_amd.parallel.actor_manager import ActorManager
+        class W:
+            def apply(self, func, *a):
+                return func(self, *a)
+        dist.init_process_group("gloo")
+        r = dist.get_rank()
+        m = ActorManager(W())
+        out = m.execute_with_actor_pool(lambda w, v: (v * v, dist.get_rank()), list(range(7)),
+                                        affinity_actors=[[1]] * 2 + [None] * 5)
+        assert [o[0] for o in out] == [v * v for v in range(7)], out
+        assert out[0][1] == 1 and out[1][1] == 1
+        assert sorted(set(o[1] for o in out)) == [0, 1, 2]
+        assert m.foreach_actor(lambda w: dist.get_rank()) == [0, 1, 2]
+        try:
+            m.execute_with_actor_pool(lambda w, v: 1 // (v - 3), list(range(6)))
+            raise SystemExit("expected a failure on every rank")
+        except RuntimeError as e:
+            assert "rank" in str(e)
+        dist.barrier()
+        if r == 0:
+            print("FARM_OK")
+    """ % REPO))
+    env = dict(os.environ, PYTHONPATH=REPO)
+    p = subprocess.run([sys.executable, "-m", "blades_amd.parallel.launcher", "--nproc", "3", "--", str(script)],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=REPO)
+    assert p.returncode == 0 and "FARM_OK" in p.stdout, p.stdout + p.stderr
+
+
+def _producer(q, n, consumed):
+    for i in range(n):
+        q.put(torch.full((4, 3), float(i)))
+    q.put("done")
+    consumed.wait(120)  # IPC rule: the producer outlives the consumer's open of its segments
+
+
+def test_queue_moves_tensors_between_processes():
+    import torch.multiprocessing as mp
+    from blades_amd.utils.queue import Empty, Queue
+
+    q = Queue(maxsize=8)
+    with pytest.raises(Empty):
+        q.get_nowait()
+    ctx = mp.get_context("spawn")
+    consumed = ctx.Event()
+    p = ctx.Process(target=_producer, args=(q._q, 3, consumed))
+    p.start()
+    got = [q.get(timeout=120) for _ in range(4)]
+    consumed.set()
+    p.join(60)
+    assert got[-1] == "done"
+    for i, t in enumerate(got[:3]):
+        assert torch.equal(t, torch.full((4, 3), float(i)))
+    q.shutdown()
+
+
+def test_reduce_mean_results():
+    rs = [{"loss": 1.0, "acc": {"top1": 0.5, "top3": [0.1, 0.2]}}, {"loss": 3.0, "acc": {"top1": 1.0, "top3": [0.3, 0.4]}}]
+    out = _reduce_mean_results(rs)
+    assert out["loss"] == 2.0 and out["acc"]["top1"] == 0.75 and np.allclose(out["acc"]["top3"], [0.2, 0.3])
+    w = _reduce_weighted_mean_results(rs, [1, 3])
+    assert abs(w["loss"] - 2.5) < 1e-12
+    assert _reduce_mean_results([]) == {}
+    with pytest.raises(ValueError):
+        _reduce_mean_results([{"a": 1}, {"b": 1}])
+
+
+def test_session_and_shims():
+    import fllib.session as S
+    from fllib.core.execution.actor_manager import ActorManager as AM  # noqa: F401
+    from fllib.utils.actor_pool import ActorPool  # noqa: F401
+    from fllib.utils.queue import Queue  # noqa: F401
+    from fllib.core.execution.reduce_result_dict_fn import _reduce_mean_results as r  # noqa: F401
+
+    with pytest.raises(Exception):
+        S._fl_session = None
+        S.get_session()
+    S.init_session()
+    assert isinstance(S.get_session(), S.FLSession)
