@@ -402,3 +402,84 @@ def test_update_forging_adversaries_gpu_match_cpu(dev, cls_name, kw, agg):
         assert torch.equal(uc[f:], ug[f:])  # benign rows untouched on both
         scale = float(uc[:f].abs().max())
         torch.testing.assert_close(ug[:f], uc[:f], rtol=2e-3, atol=2e-4 * max(1.0, scale))
+
+
+def test_kernels_are_bitwise_deterministic(dev):
+    """Deterministic mode: every HIP kernel runs twice on the same inputs and must return the same
+    bits — all reductions are two-stage with a fixed order (no float atomics), split-K partials are summed in order."""
+    from blades_amd import ops
+
+    h = ops._h()
+    g = torch.Generator().manual_seed(3)
+    K, D = 37, 20011
+    U = torch.randn(K, D, generator=g).to(dev)
+    mask = (torch.rand(K, generator=g) > 0.25).float().to(dev)
+    mask[:5] = 1
+    w = torch.rand(K, generator=g).to(dev)
+    v = torch.randn(D, generator=g).to(dev)
+
+    def same(fn, what):
+        a, b = fn(), fn()
+        a = a if isinstance(a, (tuple, list)) else (a,)
+        b = b if isinstance(b, (tuple, list)) else (b,)
+        for i, (x, y) in enumerate(zip(a, b)):
+            if x is None:
+                continue
+            assert torch.equal(x, y), f"{what}[{i}] differs between two runs"
+
+    same(lambda: ops.weighted_col_sum(U, w), "weighted_col_sum")
+    same(lambda: ops.col_mean(U, mask), "col_mean")
+    same(lambda: ops.col_mean_std(U, mask), "col_mean_std")
+    same(lambda: ops.col_min_max(U, mask), "col_min_max")
+    same(lambda: ops.col_median(U, mask), "col_median")
+    same(lambda: ops.col_trimmed_mean(U, 4, mask), "col_trimmed_mean")
+    same(lambda: ops.row_stats(U), "row_stats")
+    same(lambda: ops.row_sqnorm(U), "row_sqnorm")
+    same(lambda: ops.sqdist_to(U, v), "sqdist_to")
+    same(lambda: ops.row_dot(U, v), "row_dot")
+    same(lambda: ops.gram(U), "gram")
+    same(lambda: ops.philox_normal(4099, 5, 2, 7, 0.1, 0.2, device=dev), "philox_normal")
+    logits = torch.randn(1031, 10, generator=g).to(dev)
+    labels = torch.randint(0, 10, (1031,), generator=g).to(dev)
+    same(lambda: ops.ce_topk(logits, labels, (1, 3, 5)), "ce_topk")
+
+    def forge():
+        V = U.clone()
+        m2 = mask.clone()
+        m2[:3] = 0
+        ops.alie_forge_(V, m2, torch.arange(3, device=dev), 0.7)
+        return V
+
+    same(forge, "alie_forge_")
+
+    def step():
+        theta, buf = v.clone(), torch.zeros_like(v)
+        ops.server_step_(theta, buf, U[0], 0.1, 0.9, True)
+        ops.server_step_(theta, buf, U[1], 0.1, 0.9, False)
+        return theta, buf
+
+    same(step, "server_step_")
+
+    # training kernels: per-client BN and the split-K MFMA weight gradient
+    Kc, B, C, H = 3, 8, 64, 16
+    mk = lambda c: torch.randn(Kc * B, c, H, H, generator=g).to(dev).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    x, r, gy = mk(C), mk(C), mk(C)
+    gamma, beta = torch.rand(C, generator=g).to(dev) + 0.5, torch.randn(C, generator=g).to(dev)
+    same(lambda: h.pcbn_forward(x, r, gamma, beta, Kc, 1e-5, True, want_mask=True), "pcbn_forward")
+    y, mean, invstd, gate = h.pcbn_forward(x, r, gamma, beta, Kc, 1e-5, True, want_mask=True)
+    coef = torch.tensor([1.0, -2.0, 0.5], device=dev)
+
+    def bn_bwd():
+        Ub = torch.zeros(Kc, 2 * C + 3, device=dev)
+        dx, gres = h.pcbn_backward(x, gy, gate, gamma, mean, invstd, Kc, coef, Ub, 1, C + 2, False, True)
+        return dx, gres, Ub
+
+    same(bn_bwd, "pcbn_backward")
+
+    def wgrad():
+        Uw = torch.zeros(Kc, C * C * 9, device=dev)
+        assert h.conv_wgrad_(x, gy, Kc, Uw, 0, coef, False, 3, 1, 1)
+        return Uw
+
+    same(wgrad, "conv_wgrad_")
