@@ -114,6 +114,7 @@ class Fedavg(Algorithm):
             self.device = self.rt.device if (want_gpu or self.rt.device.type == "cuda") else torch.device("cpu")
         self._timers = PhaseTimers(self.device)
         self._counters = defaultdict(int)
+        self._allreduce_bytes_seen = 0
 
         from blades_amd.parallel.context import ShardContext
 
@@ -236,6 +237,11 @@ class Fedavg(Algorithm):
         results.update(server_return)
         results["timers"] = T.snapshot()
         results["timers"].update({k: v for k, v in self.engine.timers.items()})
+        # bytes this rank moved over RCCL this round (update-matrix exchange / small all-reduces), SURVEY §5.5
+        cs = self.ctx.stats
+        results["comm_bytes"] = {"alltoall": int(cs.get("alltoall_bytes", 0)),
+                                 "allreduce": int(cs.get("allreduce_bytes", 0)) - self._allreduce_bytes_seen}
+        self._allreduce_bytes_seen = int(cs.get("allreduce_bytes", 0))
         info = getattr(self.server.aggregator, "last_info", None)
         if info and "num_selected" in info:
             results["num_selected_clients"] = int(info["num_selected"])
