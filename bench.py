@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--clients", type=int, default=1000)
     ap.add_argument("--malicious-frac", type=float, default=0.2)
     ap.add_argument("--model", default="resnet18")
+    ap.add_argument("--dataset", default="cifar10", help="cifar10 | mnist | fashionmnist (synthetic stand-ins of that shape)")
     ap.add_argument("--aggregator", default="Median")
     ap.add_argument("--adversary", default="ALIEAdversary")
     ap.add_argument("--batch", type=int, default=64)
@@ -68,7 +69,7 @@ def main():
     root = tempfile.mkdtemp(prefix="blades_bench_")
     cfg = (FedavgConfig()
            .resources(num_gpus_for_driver=0 if args.cpu else 1)
-           .data(dataset_config={"type": "cifar10", "num_clients": K, "num_classes": 10,
+           .data(dataset_config={"type": args.dataset, "num_clients": K, "num_classes": 10,
                                  "train_batch_size": args.batch, "synthetic": True,
                                  "n_train": K * args.samples_per_client, "n_test": K * 8, "data_root": root,
                                  "use_cache": False})
@@ -144,9 +145,9 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "bf16" if args.amp == "bf16" else args.amp,
-            "data": "synthetic (CIFAR-10 shape, random-init weights)",
+            "data": f"synthetic ({args.dataset} shape, random-init weights)",
             "config": {
-                "model": args.model, "dataset": "cifar10", "num_clients": K, "num_malicious": f,
+                "model": args.model, "dataset": args.dataset, "num_clients": K, "num_malicious": f,
                 "adversary": args.adversary, "aggregator": args.aggregator, "client_batch": args.batch,
                 "global_batch": (K - f) * args.batch, "local_steps": args.local_steps, "update_dim": algo.engine.D,
                 "parallelism": f"clients sharded over {world} GPU(s); all-to-all to D-sharded aggregation",

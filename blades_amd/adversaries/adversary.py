@@ -53,7 +53,8 @@ class Adversary:
 
     def on_local_round_end(self, algorithm):
         if type(self).forge is not Adversary.forge and len(self.clients) > 0:
-            if float(algorithm.benign_mask.sum()) == 0:
+            nb = getattr(algorithm, "num_benign", None)  # host-side count; a MagicMock algorithm has only the mask
+            if (nb if isinstance(nb, int) else float(algorithm.benign_mask.sum())) == 0:
                 raise ValueError("No benign updates found. To use this adversary, you must have at least one "
                                  "benign client.")
             self.forge(algorithm, algorithm.update_matrix, algorithm.ctx)

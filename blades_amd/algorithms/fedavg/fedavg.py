@@ -142,6 +142,7 @@ class Fedavg(Algorithm):
             num_classes=dc.get("num_classes"))
         self._malicious_flags = [bool(c.is_malicious) for c in clients]
         self._benign_mask = self.engine.row_mask([not m for m in self._malicious_flags])
+        self.num_benign = int(sum(1 for m in self._malicious_flags if not m))  # host copy: no sync to ask
         self._malicious_rows = torch.nonzero(self._benign_mask == 0).flatten()
         self._malicious_row_clients = torch.as_tensor(
             self.engine.plan.client_of_row[self._malicious_rows.cpu().numpy()], dtype=torch.int64)

@@ -94,7 +94,7 @@ class BatchAugment:
 
             mean = self.normalize.mean if self.normalize else (0.0,) * x.shape[2]
             std = self.normalize.std if self.normalize else (1.0,) * x.shape[2]
-            return _hip.augment_batch(x, params.to(x.device), self.size, mean, std)
+            return _hip.augment_batch(x, params, self.size, mean, std)  # host table: validated without a sync
         return self.apply_reference(x, params)
 
     def apply_reference(self, x: torch.Tensor, params: torch.Tensor) -> torch.Tensor:

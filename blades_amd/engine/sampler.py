@@ -33,6 +33,9 @@ class DeviceSampler:
         self.epoch = np.zeros(self.K, dtype=np.int64)
         self.cursor = np.zeros(self.K, dtype=np.int64)
         self.perm = torch.zeros(self.K, max(self.nmax, 1), dtype=torch.int64, device=device)
+        # device mirror of the cursors: steady-state batches are indexed without any host->device copy
+        self.cursor_t = torch.zeros(self.K, dtype=torch.int64, device=device)
+        self._row_cache = {}
         self._ar = torch.arange(self.B, device=device)
         if self.K:
             self._reshuffle(np.arange(self.K))
@@ -52,31 +55,61 @@ class DeviceSampler:
         keys.masked_fill_(invalid, 2.0)
         self.perm[r] = keys.argsort(dim=1)
         self.cursor[rows] = 0
+        self.cursor_t[r] = 0
 
     def next_indices(self, rows: np.ndarray = None) -> torch.Tensor:
         """Global sample indices ``[len(rows), B]`` (advances those rows' cursors)."""
         if rows is None:
             rows = np.arange(self.K)
+        self.prepare(rows)
+        idx = self.gather_indices(self.rows_on_device(rows))
+        self.finish(rows)
+        return idx
+
+    # The three steps of ``next_indices``; a captured HIP graph replays the middle one (pure device work on
+    # static tensors) while the host keeps doing the outer two.
+    def rows_on_device(self, rows: np.ndarray):
+        """(r, n[r], offsets[r]) device tensors of a row set — cached, chunks repeat every round."""
+        key = rows.tobytes()
+        hit = self._row_cache.get(key)
+        if hit is None:
+            if len(self._row_cache) > 256:
+                self._row_cache.clear()
+            r = torch.as_tensor(rows, device=self.device)
+            hit = self._row_cache[key] = (r, self.n_t[r].unsqueeze(1), self.offsets_t[r].unsqueeze(1))
+        return hit
+
+    def prepare(self, rows: np.ndarray) -> None:
+        """Host bookkeeping before a batch: reshuffle the rows whose epoch is used up."""
         full = self.n[rows] >= self.B
         need = full & (self.cursor[rows] + self.B > self.n[rows])
         if need.any():
             self._reshuffle(rows[need])
-        r = torch.as_tensor(rows, device=self.device)
-        cur = torch.as_tensor(self.cursor[rows], device=self.device)
-        pos = (cur.unsqueeze(1) + self._ar.unsqueeze(0)) % self.n_t[r].unsqueeze(1)
-        idx = self.perm[r].gather(1, pos) + self.offsets_t[r].unsqueeze(1)
+
+    def gather_indices(self, dev_rows) -> torch.Tensor:
+        """Device part: indices of the next batch of every row, cursors advanced (no host data involved)."""
+        r, n_r, off_r = dev_rows
+        cur = self.cursor_t[r]
+        pos = (cur.unsqueeze(1) + self._ar.unsqueeze(0)) % n_r
+        idx = self.perm[r].gather(1, pos) + off_r
+        self.cursor_t.index_add_(0, r, torch.full_like(cur, self.B))
+        return idx
+
+    def finish(self, rows: np.ndarray) -> None:
+        """Host bookkeeping after a batch: mirror the cursor advance; wrap-around shards (smaller than a batch)
+        reshuffle once a full pass is consumed."""
         self.cursor[rows] += self.B
-        small = ~full
-        if small.any():  # wrap-around shards reshuffle once a full pass is consumed
+        small = self.n[rows] < self.B
+        if small.any():
             done = small & (self.cursor[rows] >= self.n[rows])
             if done.any():
                 self._reshuffle(rows[done])
-        return idx
 
     def state_dict(self):
         return {"cursor": self.cursor.copy(), "perm": self.perm.cpu(), "epoch": self.epoch.copy()}
 
     def load_state_dict(self, s):
         self.cursor = np.asarray(s["cursor"]).copy()
+        self.cursor_t.copy_(torch.as_tensor(self.cursor))
         self.perm.copy_(s["perm"].to(self.device))
         self.epoch = np.asarray(s["epoch"]).copy()

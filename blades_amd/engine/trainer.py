@@ -170,15 +170,39 @@ class ClientEngine:
                 spec = None
             specs.append(spec)
         self._specs, self._trains = specs, trains
+        self._row_vec_cache = {}  # per-chunk device vectors derive from the specs
+        self._spec_version = getattr(self, "_spec_version", 0) + 1
         self._malicious = [bool(getattr(self.clients[i], "is_malicious", False)) for i in self.local_ids]
 
     def _row_vectors(self, rows: np.ndarray):
         """Per-row fused settings for local rows ``rows`` (all batched)."""
+        key = rows.tobytes()
+        hit = self._row_vec_cache.get(key)
+        if hit is not None:
+            gscale, flip, gclip, self._any_flip, self._any_clip = hit
+            return gscale, flip, gclip
         sp = [self._specs[r] for r in rows]
+        flips = [s.get("label_flip", 0) for s in sp]
+        clips = [s.get("grad_clip", float("inf")) for s in sp]
         gscale = torch.tensor([s.get("grad_scale", 1.0) for s in sp], device=self.device)
-        flip = torch.tensor([s.get("label_flip", 0) for s in sp], device=self.device)
-        gclip = torch.tensor([s.get("grad_clip", float("inf")) for s in sp], device=self.device)
+        flip = torch.tensor(flips, device=self.device)
+        gclip = torch.tensor(clips, device=self.device)
+        # "is there anything to do" is decided on the host lists: asking the device tensors would be a
+        # stream-draining sync at the start of every chunk
+        self._any_flip = any(f > 0 for f in flips)
+        self._any_clip = any(np.isfinite(c) for c in clips)
+        self._row_vec_cache[key] = (gscale, flip, gclip, self._any_flip, self._any_clip)
         return gscale, flip, gclip
+
+    def _chunk_consts(self, rows: np.ndarray):
+        """(row index tensor, benign flags) of a chunk on the device — cached like the row vectors."""
+        key = (b"c", rows.tobytes())
+        hit = self._row_vec_cache.get(key)
+        if hit is None:
+            hit = self._row_vec_cache[key] = (
+                torch.as_tensor(rows, device=self.device),
+                torch.tensor([not self._malicious[r] for r in rows], device=self.device))
+        return hit
 
     # ------------------------------------------------------------------
     def _params_from_flat(self, flat: torch.Tensor, batched: bool = False) -> Dict[str, torch.Tensor]:
@@ -213,7 +237,7 @@ class ClientEngine:
                 X = tf.apply(X, tf.draw(Kc, None, X.shape[-2], X.shape[-1], uniforms=self._aug_uniforms(srows, tf)))
             else:
                 X = torch.stack([tf(X[c]) for c in range(Kc)])
-        if bool((flip > 0).any()):
+        if self._any_flip:
             Y = torch.where(flip.unsqueeze(1) > 0, flip.unsqueeze(1) - 1 - Y, Y)
         return X, Y
 
@@ -243,9 +267,9 @@ class ClientEngine:
     def _train_chunk_fedsgd(self, theta, rows, srows):
         gscale, flip, gclip = self._row_vectors(rows)
         X, Y = self._fetch_batch(srows, flip)
-        rows_t = torch.as_tensor(rows, device=self.device)
+        rows_t = self._chunk_consts(rows)[0]
         contiguous = int(rows[-1] - rows[0]) == len(rows) - 1
-        plain = self.momentum == 0.0 and not bool(torch.isfinite(gclip).any())
+        plain = self.momentum == 0.0 and not self._any_clip
         if self.fused is not None:
             # per-client gradients land in the rows of U directly, pre-scaled
             block = self.U_row[int(rows[0]): int(rows[-1]) + 1] if contiguous else torch.empty(
@@ -263,7 +287,7 @@ class ClientEngine:
             self._flatten_into(grads, G)
             del grads
             contiguous = False
-        if bool(torch.isfinite(gclip).any()):
+        if self._any_clip:
             gscale = gscale * self._clip_coef(ops.row_sqnorm(G), gclip)
         if self.momentum != 0.0:
             if self.M is None:
@@ -302,7 +326,7 @@ class ClientEngine:
                 self._flatten_into(grads, G)
                 del grads
             gs = gscale0
-            if bool(torch.isfinite(gclip).any()):
+            if self._any_clip:
                 gs = gs * self._clip_coef(ops.row_sqnorm(G), gclip)
             first = (not self._mom_init) and step == 0
             ops.client_sgd_step_(W, G, Mv, self.lr, self.momentum, first, gs)
@@ -342,7 +366,11 @@ class ClientEngine:
         seq = [k for k, r in enumerate(self._train_rows) if self._specs[r] is None]
         nontrain = [r for r in range(self.Kloc) if not self._trains[r]]
         if nontrain:
-            self.U_row[torch.as_tensor(nontrain, device=dev)] = 0
+            key = (b"n", self._spec_version)
+            nt = self._row_vec_cache.get(key)
+            if nt is None:
+                nt = self._row_vec_cache[key] = torch.as_tensor(nontrain, device=dev)
+            self.U_row[nt] = 0
         # rows whose content is final only at the end of the round (sequential clients, round-end hooks):
         # with any of those the exchange cannot start early
         late = bool(seq) or self._has_round_end_hooks()
@@ -364,7 +392,7 @@ class ClientEngine:
                         losses = self._train_chunk_fedsgd(theta, rows, ks)
                     else:
                         losses = self._train_chunk_general(theta, rows, ks)
-                    benign = torch.tensor([not self._malicious[r] for r in rows], device=dev)
+                    benign = self._chunk_consts(rows)[1]
                     pending.append(((losses.double() * benign).sum(), benign.sum()))
                 if st is None and not late and c0 + self.chunk < len(batched):
                     # everything below the next untrained row is final: ship it while the next chunk trains
@@ -415,8 +443,9 @@ class ClientEngine:
             return
         rt = torch.as_tensor(rows, device=self.device)
         blk = self.U_row[rt][:, : self.D].contiguous()
-        clip = torch.tensor([self._specs[r].get("update_clip", float("inf")) for r in rows], device=self.device)
-        if bool(torch.isfinite(clip).any()):
+        clips = [self._specs[r].get("update_clip", float("inf")) for r in rows]
+        clip = torch.tensor(clips, device=self.device)
+        if any(np.isfinite(c) for c in clips):
             ops.row_scale_(blk, self._clip_coef(ops.row_sqnorm(blk), clip))
         stds = {self._specs[r].get("update_noise_std", 0.0) for r in rows}
         for std in stds:

@@ -90,11 +90,29 @@ def _ptr(t: Optional[torch.Tensor]):
     return c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else c_void_p(0)
 
 
+_rows_checked = {}  # id(tensor) -> (weakref, version, K, validated device copy)
+
+
 def _rows(rows: torch.Tensor, K: int, device) -> torch.Tensor:
+    """Row-index vector for a kernel, range-checked on the host.  A device tensor is checked once (that costs
+    a device->host copy, i.e. a stream sync) and remembered while it is alive and unmodified: the per-round
+    callers (the adversaries' ``malicious_rows``) pass the same tensor every round."""
+    if rows.is_cuda:
+        hit = _rows_checked.get(id(rows))
+        if hit is not None and hit[0]() is rows and hit[1] == rows._version and hit[2] == K:
+            return hit[3]
+    src = rows
     rows = rows.to(device="cpu", dtype=torch.int64).flatten()
     if rows.numel() and (int(rows.min()) < 0 or int(rows.max()) >= K):
         raise IndexError("row index out of range")
-    return rows.to(device).contiguous()
+    out = rows.to(device).contiguous()
+    if src.is_cuda:
+        import weakref
+
+        if len(_rows_checked) > 64:
+            _rows_checked.clear()
+        _rows_checked[id(src)] = (weakref.ref(src), src._version, K, out)
+    return out
 
 
 # ---------------------------------------------------------------------------
@@ -291,10 +309,11 @@ def augment_batch(x, params, size, mean, std):
         raise ValueError("augment_batch: x must be CUDA fp32 [n, B, C, H, W]")
     x = x.contiguous()
     n, B, C, H, W = x.shape
-    params = params.to(device=x.device, dtype=torch.float32).contiguous()
     if params.shape != (n, 9):
         raise ValueError("augment_batch: params must be [n, 9]")
-    pc = params.cpu()
+    # validated on the host copy: a table that already lives on the host (the engine's case) costs no device sync
+    pc = params.detach().float().cpu()
+    params = params.to(device=x.device, dtype=torch.float32).contiguous()
     # crop window must lie inside the image (checked on the host: see module docstring)
     if n and (float((pc[:, 0] + pc[:, 2]).max()) > H or float((pc[:, 1] + pc[:, 2]).max()) > W
               or float(pc[:, :3].min()) < 0 or float(pc[:, 2].min()) < 1):
