@@ -94,8 +94,19 @@ class BatchAugment:
 
             mean = self.normalize.mean if self.normalize else (0.0,) * x.shape[2]
             std = self.normalize.std if self.normalize else (1.0,) * x.shape[2]
-            return _hip.augment_batch(x, params, self.size, mean, std)  # host table: validated without a sync
+            # a host table is validated right here without a sync; a device table must have been check()ed by
+            # whoever filled it (the engine's HIP-graph path uploads a checked host table into a static buffer)
+            return _hip.augment_batch(x, params, self.size, mean, std, validate=not params.is_cuda)
         return self.apply_reference(x, params)
+
+    @staticmethod
+    def check(params: torch.Tensor, height: int, width: int) -> None:
+        """Host-side validity check of a parameter table (crop windows inside the image)."""
+        pc = params.detach().float().cpu()
+        if pc.shape[0] and (float((pc[:, P_I] + pc[:, P_S]).max()) > height
+                            or float((pc[:, P_J] + pc[:, P_S]).max()) > width
+                            or float(pc[:, :3].min()) < 0 or float(pc[:, P_S].min()) < 1):
+            raise ValueError("augmentation table: crop window out of bounds")
 
     def apply_reference(self, x: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
         n, B, C, H, W = x.shape

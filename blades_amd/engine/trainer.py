@@ -40,6 +40,11 @@ from .plan import RowPlan, make_plan
 from .sampler import DeviceSampler
 
 
+def store_hw(store):
+    """(H, W) of the samples of a DeviceStore."""
+    return int(store.x.shape[-2]), int(store.x.shape[-1])
+
+
 def _autocast(device: torch.device, dtype: Optional[torch.dtype]):
     if dtype is None or dtype == torch.float32:
         return torch.autocast(device_type=device.type, enabled=False)
@@ -121,6 +126,12 @@ class ClientEngine:
         self.U_col = self.U_row if G == 1 else torch.zeros(self.K, self.Dl, dtype=torch.float32,
                                                             device=self.device)
         self.n_streams = max(1, int(os.environ.get("BLADES_CHUNK_STREAMS", "1")))
+        # HIP-graph capture of a FedSGD chunk (see _graphed_chunk): "auto" turns it on for launch-bound rounds
+        self.hip_graphs = os.environ.get("BLADES_HIP_GRAPH", "auto").lower()
+        self._chunk_graphs = {}
+        self._graph_pool = None
+        self._graph_failed = False
+        self.graph_replays = 0
         self._streams = None
         self.M = None  # per-client momentum buffers [Kloc_train, D], lazily
         self._mom_init = False
@@ -264,7 +275,92 @@ class ClientEngine:
             out[:, int(o): int(o) + m].copy_(grads[n].reshape(Kc, m))
 
     # ------------------------------------------------------------------
+    # -- HIP-graph path ---------------------------------------------------------------------------------------
+    # Small rounds (the reference's 60-client experiments on an MLP / small CNN / ResNet-10) are bound by
+    # kernel-launch latency, not by the GPU: a chunk is a few hundred launches of microsecond kernels.  Such a
+    # chunk is captured once — batch gather from the device-resident sampler, augmentation, the fused
+    # forward/backward with its per-client gradient kernels writing into the update-matrix rows — and replayed
+    # as one hipGraphLaunch per round.  Everything the graph reads lives at fixed addresses (theta, the sample
+    # store, permutation table and cursors, U rows); the only per-round host input is the augmentation table.
+    def _graphs_wanted(self) -> bool:
+        if self.hip_graphs in ("0", "off", "false") or self._graph_failed:
+            return False
+        if self.device.type != "cuda" or self.fused is None or self.nb != 1 or self.momentum != 0.0:
+            return False
+        if self.hip_graphs in ("1", "on", "true"):
+            return True
+        # auto: per-round work small enough that launches dominate (ResNet-10 x 60 clients yes, the 1000-client
+        # ResNet-18 headline no — there the GPU is saturated and a graph would only pin activation memory)
+        return len(self._train_rows) * self.B * self.D <= 5e10
+
+    def _graphed_chunk(self, rows, srows):
+        """Replays (capturing on the third visit) the HIP graph of this chunk; ``None`` = not graphable."""
+        tf = self.dataset.train_transform
+        aug = tf is not None and hasattr(tf, "draw")
+        if tf is not None and not aug:
+            return None
+        if int(rows[-1] - rows[0]) != len(rows) - 1:
+            return None
+        gscale, flip, gclip = self._row_vectors(rows)
+        if self._any_clip:
+            return None
+        key = (rows.tobytes(), srows.tobytes(), self._spec_version)
+        ent = self._chunk_graphs.get(key)
+        if ent is None:
+            if len(self._chunk_graphs) > 64:
+                self._chunk_graphs.clear()
+            ent = self._chunk_graphs[key] = {"visits": 0, "graph": None}
+        ent["visits"] += 1
+        if ent["graph"] is None and ent["visits"] <= 2:
+            return None  # eager first: MIOpen kernel search, wgrad plans and scratch buffers settle outside capture
+        Kc = len(rows)
+        if ent["graph"] is None:
+            any_flip = self._any_flip
+            dev_rows = self.sampler.rows_on_device(srows)
+            block = self.U_row[int(rows[0]): int(rows[-1]) + 1]
+            scale = (-self.lr * gscale).float()
+            store = self.train_store
+            params = torch.zeros(Kc, 9, device=self.device) if aug else None  # transforms.N_PARAMS columns
+
+            def body():
+                idx = self.sampler.gather_indices(dev_rows).reshape(-1)
+                X = store.x[idx].reshape(Kc, self.B, *store.x.shape[1:])
+                Y = store.y[idx].reshape(Kc, self.B)
+                if aug:
+                    X = tf.apply(X, params)
+                if any_flip:
+                    Y = torch.where(flip.unsqueeze(1) > 0, flip.unsqueeze(1) - 1 - Y, Y)
+                return self.fused.run(X, Y, block, scale)
+
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, pool=self._graph_pool):
+                    losses = body()
+            except Exception as e:  # noqa: BLE001 — anything not capturable: stay eager for good
+                self._graph_failed = True
+                self._graph_error = repr(e)
+                self._chunk_graphs.clear()
+                torch.cuda.synchronize()
+                return None
+            ent.update(graph=g, losses=losses, params=params)
+        self.sampler.prepare(srows)
+        if aug:
+            table = tf.draw(Kc, None, store_hw(self.train_store)[0], store_hw(self.train_store)[1],
+                            uniforms=self._aug_uniforms(srows, tf))
+            tf.check(table, *store_hw(self.train_store))
+            ent["params"].copy_(table)
+        ent["graph"].replay()
+        self.graph_replays += 1
+        self.sampler.finish(srows)
+        return ent["losses"]
+
     def _train_chunk_fedsgd(self, theta, rows, srows):
+        if self._graphs_wanted():
+            losses = self._graphed_chunk(rows, srows)
+            if losses is not None:
+                return losses
         gscale, flip, gclip = self._row_vectors(rows)
         X, Y = self._fetch_batch(srows, flip)
         rows_t = self._chunk_consts(rows)[0]

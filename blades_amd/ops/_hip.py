@@ -304,7 +304,7 @@ def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, over
     return U
 
 
-def augment_batch(x, params, size, mean, std):
+def augment_batch(x, params, size, mean, std, validate: bool = True):
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5):
         raise ValueError("augment_batch: x must be CUDA fp32 [n, B, C, H, W]")
     x = x.contiguous()
@@ -312,10 +312,10 @@ def augment_batch(x, params, size, mean, std):
     if params.shape != (n, 9):
         raise ValueError("augment_batch: params must be [n, 9]")
     # validated on the host copy: a table that already lives on the host (the engine's case) costs no device sync
-    pc = params.detach().float().cpu()
+    pc = params.detach().float().cpu() if validate else None
     params = params.to(device=x.device, dtype=torch.float32).contiguous()
     # crop window must lie inside the image (checked on the host: see module docstring)
-    if n and (float((pc[:, 0] + pc[:, 2]).max()) > H or float((pc[:, 1] + pc[:, 2]).max()) > W
+    if n and validate and (float((pc[:, 0] + pc[:, 2]).max()) > H or float((pc[:, 1] + pc[:, 2]).max()) > W
               or float(pc[:, :3].min()) < 0 or float(pc[:, 2].min()) < 1):
         raise ValueError("augment_batch: crop window out of bounds")
     out = torch.empty(n, B, C, size, size, device=x.device, dtype=torch.float32)
