@@ -65,6 +65,15 @@ class _PCConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, mod):
         w = weight.to(x.dtype)
         b = mod.bias.to(x.dtype) if mod.bias is not None else None
+        if x.is_cuda and x.dim() == 4:
+            # keep the whole network in NHWC: MIOpen's bf16 kernels are NHWC (an NCHW input is transposed
+            # around every call) and so are the per-client BN / wgrad kernels.  A one-channel image is
+            # "contiguous" in both layouts and PyTorch then assumes NCHW — say NHWC through the strides.
+            if x.shape[1] == 1 and x.is_contiguous():
+                x = x.as_strided(x.shape, (x.stride(0), 1, x.stride(2), x.stride(3)))
+            else:
+                x = x.contiguous(memory_format=torch.channels_last)
+            w = w.contiguous(memory_format=torch.channels_last)
         ctx.mod = mod
         ctx.save_for_backward(x, w)
         return F.conv2d(x, w, b, mod.stride, mod.padding, mod.dilation, 1)
@@ -83,7 +92,9 @@ class _PCConvFn(torch.autograd.Function):
         if not mod.wgrad_hip(x, gy, Kc):
             sink.write(mod.weight, mod.wgrad(x, gy, Kc, B))  # [Kc, Cout, Cin, kh, kw]
         if mod.bias is not None:
-            sink.write(mod.bias, gy.float().reshape(Kc, B, gy.shape[1], -1).sum(dim=(1, 3)))
+            # per-client bias gradient: fp32 accumulation straight from the (NHWC) bf16 tensor, no fp32 copy
+            g = gy.permute(0, 2, 3, 1) if gy.dim() == 4 else gy.unsqueeze(1)
+            sink.write(mod.bias, g.reshape(Kc, -1, gy.shape[1]).sum(dim=1, dtype=torch.float32))
         return dx, None, None
 
 
@@ -155,7 +166,7 @@ class _PCLinearFn(torch.autograd.Function):
         x3 = x.reshape(Kc, -1, x.shape[-1])  # [Kc, B*, in]
         sink.write(mod.weight, torch.bmm(g3.transpose(1, 2), x3))
         if mod.bias is not None:
-            sink.write(mod.bias, g3.float().sum(dim=1))
+            sink.write(mod.bias, g3.sum(dim=1, dtype=torch.float32))
         return dx, None, None
 
 

@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2):
+def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2, server_lr=0.0):
     from blades_amd.algorithms.fedavg import FedavgConfig
 
     old = os.environ.get("BLADES_HIP_GRAPH")
@@ -19,7 +19,7 @@ def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2):
                                      "n_train": K * 20, "n_test": K * 8, "data_root": str(tmp_path),
                                      "use_cache": False})
                .training(global_model=model, server_config={"aggregator": {"type": "Median"},
-                                                            "optimizer": {"lr": 0.1, "momentum": 0.9}})
+                                                            "optimizer": {"lr": server_lr, "momentum": 0.0}})
                .client(client_config={"lr": 1.0})
                .adversary(num_malicious_clients=f, adversary_config={"type": f"blades.adversaries.{adv}"})
                .evaluation(evaluation_interval=0))
@@ -27,7 +27,8 @@ def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2):
         algo = cfg.build()
         losses = [algo.train()["train_loss"] for _ in range(rounds)]
         torch.cuda.synchronize()
-        return algo.server.theta[: algo.engine.D].clone(), losses, algo.engine
+        # with server lr 0 the weights never move: every round's loss and update rows depend on the data path only
+        return algo.update_matrix[:, : algo.engine.D].clone(), losses, algo.engine
     finally:
         if old is None:
             os.environ.pop("BLADES_HIP_GRAPH", None)
@@ -53,21 +54,22 @@ def test_graph_replay_matches_eager_bitwise(tmp_path, ds, model, adv):
         # then reproduce it bit for bit
         assert loss_g == loss_e
         assert torch.equal(th_g, th_e)
-    else:
-        # Dropout2d (the graph-safe RNG stream differs from the eager one) or run-to-run solver choice: same
-        # batches and same maths within bf16 noise — a wrong batch or a stale buffer moves the loss by >> 1e-2
-        tol = 0.5 if model == "cnn" else 2e-2
+    elif model != "cnn":
+        # run-to-run solver choice: same batches, same augmentation, same maths within bf16 noise — a wrong
+        # batch or a stale buffer moves the loss by >> 1e-2 and decorrelates the update rows
         noise = max(abs(a - b) for a, b in zip(loss_e, loss_e2))
-        assert max(abs(a - b) for a, b in zip(loss_g, loss_e)) <= max(tol, 3 * noise), (loss_g, loss_e, loss_e2)
-        if model != "cnn":
-            cos = torch.nn.functional.cosine_similarity(th_g, th_e, dim=0)
-            assert float(cos) > 0.999
+        assert max(abs(a - b) for a, b in zip(loss_g, loss_e)) <= max(2e-3, 3 * noise), (loss_g, loss_e, loss_e2)
+        cos = torch.nn.functional.cosine_similarity(th_g, th_e, dim=1)
+        assert float(cos.min()) > 0.99, cos
+    else:
+        # Dropout2d: the graph-safe RNG stream differs from the eager one, so only the statistics agree
+        assert max(abs(a - b) for a, b in zip(loss_g, loss_e)) < 0.3, (loss_g, loss_e)
 
 
 def test_auto_mode_picks_graphs_only_for_small_rounds(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    _, _, eng = _run(tmp_path, "auto", "mnist", "mlp", "ALIEAdversary", rounds=5)
+    _, _, eng = _run(tmp_path, "auto", "mnist", "mlp", "ALIEAdversary", rounds=5, server_lr=0.1)
     assert eng.graph_replays >= 3, getattr(eng, "_graph_error", None)
     eng.D_saved, eng.D = eng.D, 10 ** 12  # pretend the model is huge
     assert not eng._graphs_wanted()
