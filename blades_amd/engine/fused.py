@@ -60,6 +60,18 @@ class GradSink:
 
 
 # ---------------------------------------------------------------------------
+_DGRAD_AS_FWD = _os.environ.get("BLADES_DGRAD_AS_FWD", "1") != "0"
+
+
+def dgrad_same_conv(gy: torch.Tensor, w: torch.Tensor, padding) -> torch.Tensor:
+    """Data gradient of a stride-1, dilation-1 convolution with odd kernel and ``padding = k // 2``:
+    ``dx = conv2d(gy, flip_hw(w)^T)`` with the same padding."""
+    wt = w.transpose(0, 1).flip(2, 3)
+    if gy.is_cuda:
+        wt = wt.contiguous(memory_format=torch.channels_last)
+    return F.conv2d(gy, wt, None, 1, padding, 1, 1)
+
+
 class _PCConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mod):
@@ -87,8 +99,19 @@ class _PCConvFn(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last) if gy.dim() == 4 else gy
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(
-                gy, x, w, None, mod.stride, mod.padding, mod.dilation, False, [0, 0], 1, [True, False, False])[0]
+            ks = w.shape[2:]
+            same = (gy.is_cuda and _DGRAD_AS_FWD and tuple(mod.stride) == (1, 1) and tuple(mod.dilation) == (1, 1)
+                    and ks[0] % 2 == 1 and ks[1] % 2 == 1
+                    and tuple(mod.padding) == (ks[0] // 2, ks[1] // 2))
+            if same:
+                # stride-1 "same" convolution: the data gradient is itself a forward convolution of gy with the
+                # spatially flipped, in/out-transposed filter.  MIOpen's forward kernels (CK xdl) run this
+                # shape ~1.4x faster than its backward-data igemm and need no zero-fill of dx beforehand.
+                dx = dgrad_same_conv(gy, w, mod.padding)
+            else:
+                dx = torch.ops.aten.convolution_backward(
+                    gy, x, w, None, mod.stride, mod.padding, mod.dilation, False, [0, 0], 1,
+                    [True, False, False])[0]
         if not mod.wgrad_hip(x, gy, Kc):
             sink.write(mod.weight, mod.wgrad(x, gy, Kc, B))  # [Kc, Cout, Cin, kh, kw]
         if mod.bias is not None:

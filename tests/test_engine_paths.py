@@ -91,3 +91,19 @@ def test_grouped_local_steps_equal_vectorised(data_root, model, expect_grouped):
         rel = (Ua - Ub).norm(dim=1) / Ub.norm(dim=1)
         assert float(cos.min()) > tol_cos, (rnd, cos)
         assert float(rel.max()) < tol_rel, (rnd, rel)
+
+
+def test_dgrad_as_forward_conv_matches_autograd():
+    """engine/fused.py computes the data gradient of stride-1 "same" convolutions as a forward convolution with
+    the flipped, transposed filter: must equal autograd's."""
+    import torch
+    from blades_amd.engine.fused import dgrad_same_conv
+
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, k in ((3, 5, 3), (4, 4, 1), (2, 6, 5)):
+        x = torch.randn(2, cin, 9, 7, generator=g, requires_grad=True)
+        w = torch.randn(cout, cin, k, k, generator=g)
+        y = torch.nn.functional.conv2d(x, w, None, 1, k // 2)
+        gy = torch.randn(y.shape, generator=g)
+        (ref,) = torch.autograd.grad(y, x, gy)
+        torch.testing.assert_close(dgrad_same_conv(gy, w, (k // 2, k // 2)), ref, rtol=1e-4, atol=1e-4)
