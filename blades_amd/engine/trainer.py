@@ -564,19 +564,44 @@ class ClientEngine:
     # sends/receives to all peers — xGMI is a full mesh, so all 7 links of a GPU carry data at once — and
     # lands directly in the receiver's rows of ``U_col``.  All ranks issue the same ``P`` batches in the same
     # order; which rows a piece covers follows from the (globally known) rows-per-rank table alone.
-    def _piece_bounds(self, k_rank: int, j: int):
+    # Rows of clients that do not train (update-forging attackers: a fifth of the matrix in the headline
+    # configuration) are all-zero until the adversary overwrites them *after* the exchange, so they are not
+    # sent: each rank ships only the span [lo, hi) of its block that holds its training rows, and every
+    # receiver zeroes the rest of the sender's block locally.  The spans follow from the plan and the clients'
+    # ``local_training`` flags, which every rank knows for all clients.
+    def _piece_bounds(self, span, j: int):
+        lo, hi = span
         P = self._n_pieces
-        return (j * k_rank) // P, ((j + 1) * k_rank) // P
+        return lo + (j * (hi - lo)) // P, lo + ((j + 1) * (hi - lo)) // P
+
+    def _send_spans(self):
+        key = ("spans", self._spec_version)
+        hit = self._row_vec_cache.get(key)
+        if hit is None:
+            spans = []
+            for q in range(self.rt.world_size):
+                flags = [bool(getattr(self.clients[c], "local_training", True)) for c in self.plan.rank_clients[q]]
+                idx = [i for i, f in enumerate(flags) if f]
+                spans.append((idx[0], idx[-1] + 1) if idx else (0, 0))
+            hit = self._row_vec_cache[key] = spans
+        return hit
 
     def _exchange_begin(self):
         if not self.ctx.distributed:
             return
         rows = self.plan.rows_per_rank()
-        self._n_pieces = max(1, -(-max(rows) // self.chunk))
+        self._spans = self._send_spans()
+        self._n_pieces = max(1, -(-max(hi - lo for lo, hi in self._spans) // self.chunk))
         self._next_piece = 0
         self._works = []
         self._send_keep = []
         self.ctx.stats["alltoall_bytes"] = 0
+        row_off = np.concatenate([[0], np.cumsum(rows)])
+        for q, (lo, hi) in enumerate(self._spans):  # rows nobody sends: zero (all ranks agree on which)
+            if lo > 0:
+                self.U_col[row_off[q]: row_off[q] + lo].zero_()
+            if hi < rows[q]:
+                self.U_col[row_off[q] + hi: row_off[q + 1]].zero_()
 
     def _exchange_upto(self, ready_rows: int):
         """Issue (asynchronously) every not-yet-sent piece that lies entirely below local row ``ready_rows``."""
@@ -587,7 +612,7 @@ class ClientEngine:
         row_off = np.concatenate([[0], np.cumsum(rows)])
         while self._next_piece < self._n_pieces:
             j = self._next_piece
-            a, b = self._piece_bounds(self.Kloc, j)
+            a, b = self._piece_bounds(self._spans[me], j)
             if b > ready_rows:
                 break
             self._next_piece += 1
@@ -604,7 +629,7 @@ class ClientEngine:
             for q in range(G):
                 if q == me:
                     continue
-                qa, qb = self._piece_bounds(rows[q], j)
+                qa, qb = self._piece_bounds(self._spans[q], j)
                 if qb > qa:
                     ops_.append(dist.P2POp(dist.irecv, self.U_col[row_off[q] + qa: row_off[q] + qb], q))
             if ops_:
