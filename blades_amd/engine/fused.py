@@ -303,6 +303,88 @@ def _hipmod():
     return ops._h()
 
 
+# ---------------------------------------------------------------------------
+# Transformer pieces (CCT / CVT / ViT-lite, reference fllib/models/backbones/cctnets): with shared weights the
+# attention itself has no parameters, so only LayerNorm's affine pair and the broadcast embeddings need a
+# per-client gradient; the token mixing runs as one big batch over all clients of the chunk.
+class _PCLayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        xf = x.float()
+        w = mod.weight.float() if mod.weight is not None else None
+        b = mod.bias.float() if mod.bias is not None else None
+        y, mean, rstd = torch.native_layer_norm(xf, mod.normalized_shape, w, b, mod.eps)
+        ctx.mod = mod
+        ctx.save_for_backward(x, mean, rstd)
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd = ctx.saved_tensors
+        mod = ctx.mod
+        sink: GradSink = mod.sink
+        Kc = sink.Kc
+        xf, g = x.float(), gy.float()
+        w = mod.weight.float() if mod.weight is not None else None
+        dx = torch.ops.aten.native_layer_norm_backward(g, xf, list(mod.normalized_shape), mean, rstd, w, None,
+                                                       [True, False, False])[0]
+        if mod.weight is not None:
+            xhat = (xf - mean) * rstd
+            shp = (Kc, -1) + tuple(mod.normalized_shape)
+            sink.write(mod.weight, (g * xhat).reshape(shp).sum(dim=1))
+            if mod.bias is not None:
+                sink.write(mod.bias, g.reshape(shp).sum(dim=1))
+        return dx.to(x.dtype), None
+
+
+class PCLayerNorm(nn.Module):
+    def __init__(self, ln: nn.LayerNorm, sink: GradSink):
+        super().__init__()
+        self.weight, self.bias = ln.weight, ln.bias
+        self.normalized_shape, self.eps, self.sink = tuple(ln.normalized_shape), ln.eps, sink
+
+    def forward(self, x):
+        return _PCLayerNormFn.apply(x, self)
+
+
+class _PCBroadcastFn(torch.autograd.Function):
+    """``p`` ([1, ...], shared by every sample) expanded over the batch; backward leaves each client's sum of the
+    incoming gradient in its update row."""
+
+    @staticmethod
+    def forward(ctx, p, proxy, n, dtype):
+        ctx.proxy = proxy
+        return p.to(dtype).expand(n, *p.shape[1:])
+
+    @staticmethod
+    def backward(ctx, g):
+        proxy = ctx.proxy
+        sink: GradSink = proxy.sink
+        sink.write(proxy.param, g.float().reshape(sink.Kc, -1, *g.shape[1:]).sum(dim=1))
+        return None, None, None, None
+
+
+class PCParam:
+    """Stands in for a bare ``nn.Parameter`` of shape ``[1, ...]`` that a model broadcasts over its batch
+    (positional / class embeddings): supports ``x + p``, ``p + x`` and ``p.expand(n, -1, ...)``."""
+
+    def __init__(self, param: nn.Parameter, sink: GradSink):
+        self.param, self.sink = param, sink
+        self.shape = param.shape
+
+    def _bcast(self, n, dtype):
+        return _PCBroadcastFn.apply(self.param, self, int(n), dtype)
+
+    def __radd__(self, x):
+        return x + self._bcast(x.shape[0], x.dtype)
+
+    __add__ = __radd__
+
+    def expand(self, *sizes):
+        sizes = sizes[0] if len(sizes) == 1 and isinstance(sizes[0], (tuple, list)) else sizes
+        return self._bcast(sizes[0], self.param.dtype)
+
+
 class PCBatchNorm2d(nn.Module):
     def __init__(self, bn: nn.BatchNorm2d, sink: GradSink):
         super().__init__()
@@ -363,8 +445,25 @@ def supports(model: nn.Module) -> bool:
             continue
         if isinstance(m, nn.BatchNorm2d) and not m.track_running_stats:
             continue
+        if isinstance(m, nn.LayerNorm):
+            continue
+        if _broadcast_params(m) is not None:
+            continue
         return False
     return True
+
+
+def _broadcast_params(m: nn.Module):
+    """Names of the bare parameters of ``m`` when all of them are ``[1, ...]`` tensors the module broadcasts over
+    its batch (the transformer classifier's positional / class embedding); ``None`` if ``m`` is anything else."""
+    from blades_amd.models.cctnets.layers import TransformerClassifier
+
+    if not isinstance(m, TransformerClassifier):
+        return None
+    names = [n for n, p in m.named_parameters(recurse=False)]
+    if all(n in ("positional_emb", "class_emb") for n in names):
+        return names
+    return None
 
 
 def build_template(model: nn.Module, sink: GradSink) -> nn.Module:
@@ -379,7 +478,15 @@ def build_template(model: nn.Module, sink: GradSink) -> nn.Module:
                 setattr(mod, name, PCLinear(child, sink))
             elif isinstance(child, nn.BatchNorm2d):
                 setattr(mod, name, PCBatchNorm2d(child, sink))
+            elif isinstance(child, nn.LayerNorm):
+                setattr(mod, name, PCLayerNorm(child, sink))
             else:
+                names = _broadcast_params(child)
+                for pn in names or []:
+                    prm = child._parameters[pn]
+                    if prm is not None and prm.requires_grad:
+                        del child._parameters[pn]
+                        setattr(child, pn, PCParam(prm, sink))
                 swap(child)
 
     holder = nn.Module()

@@ -32,9 +32,17 @@ def one_round_updates(algo):
     return algo.update_matrix[:, : algo.engine.D].clone(), algo.server.theta[: algo.engine.D].clone()
 
 
-@pytest.mark.parametrize("model", ["resnet", "cnn", "mlp"])
+def _no_random_drops(net):
+    from blades_amd.models.cctnets.layers import DropPath
+
+    for m in net.modules():
+        if isinstance(m, (torch.nn.modules.dropout._DropoutNd, DropPath)):
+            m.p = 0.0
+
+
+@pytest.mark.parametrize("model", ["resnet", "cnn", "mlp", "cct"])
 def test_fused_equals_vectorised(data_root, model):
-    ds = "cifar10" if model == "resnet" else "fashionmnist"
+    ds = "cifar10" if model in ("resnet", "cct") else "fashionmnist"
     a = build(data_root, model, "fused", ds)
     b = build(data_root, model, "vmap", ds)
     assert a.engine.fused is not None and b.engine.fused is None
@@ -43,6 +51,10 @@ def test_fused_equals_vectorised(data_root, model):
         algo.engine.model.apply(lambda m: setattr(m, "p", 0.0) if isinstance(m, torch.nn.modules.dropout._DropoutNd) else None)
         if algo.engine.fused is not None:
             algo.engine.fused.template.apply(lambda m: setattr(m, "p", 0.0) if isinstance(m, torch.nn.modules.dropout._DropoutNd) else None)
+        for net in (algo.engine.task.model, algo.engine.model,
+                    algo.engine.fused.template if algo.engine.fused is not None else None):
+            if net is not None:
+                _no_random_drops(net)
     Ua, ta = one_round_updates(a)
     Ub, tb = one_round_updates(b)
     torch.testing.assert_close(Ua, Ub, rtol=1e-3, atol=2e-5)
