@@ -308,33 +308,42 @@ def _hipmod():
 # attention itself has no parameters, so only LayerNorm's affine pair and the broadcast embeddings need a
 # per-client gradient; the token mixing runs as one big batch over all clients of the chunk.
 class _PCLayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dimension with per-client affine gradients.  Written with plain reductions:
+    ATen's row-moments kernel needs 0.56 ms for the 196k x 128 rows of a CCT chunk on gfx950, five fused
+    elementwise/reduce passes need less than half of that."""
+
     @staticmethod
     def forward(ctx, x, mod):
+        if len(mod.normalized_shape) != 1:
+            raise NotImplementedError("PCLayerNorm normalises the last dimension only")
         xf = x.float()
-        w = mod.weight.float() if mod.weight is not None else None
-        b = mod.bias.float() if mod.bias is not None else None
-        y, mean, rstd = torch.native_layer_norm(xf, mod.normalized_shape, w, b, mod.eps)
+        var, mean = torch.var_mean(xf, dim=-1, unbiased=False, keepdim=True)
+        rstd = torch.rsqrt(var + mod.eps)
+        xhat = (xf - mean) * rstd
+        y = xhat
+        if mod.weight is not None:
+            y = y * mod.weight.float()
+        if mod.bias is not None:
+            y = y + mod.bias.float()
         ctx.mod = mod
-        ctx.save_for_backward(x, mean, rstd)
+        ctx.save_for_backward(xhat.to(x.dtype), rstd)
         return y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, gy):
-        x, mean, rstd = ctx.saved_tensors
+        xhat, rstd = ctx.saved_tensors
         mod = ctx.mod
         sink: GradSink = mod.sink
         Kc = sink.Kc
-        xf, g = x.float(), gy.float()
-        w = mod.weight.float() if mod.weight is not None else None
-        dx = torch.ops.aten.native_layer_norm_backward(g, xf, list(mod.normalized_shape), mean, rstd, w, None,
-                                                       [True, False, False])[0]
+        xh, g = xhat.float(), gy.float()
+        C = xh.shape[-1]
         if mod.weight is not None:
-            xhat = (xf - mean) * rstd
-            shp = (Kc, -1) + tuple(mod.normalized_shape)
-            sink.write(mod.weight, (g * xhat).reshape(shp).sum(dim=1))
+            sink.write(mod.weight, (g * xh).reshape(Kc, -1, C).sum(dim=1))
             if mod.bias is not None:
-                sink.write(mod.bias, g.reshape(shp).sum(dim=1))
-        return dx.to(x.dtype), None
+                sink.write(mod.bias, g.reshape(Kc, -1, C).sum(dim=1))
+            g = g * mod.weight.float()
+        dx = rstd * (g - g.mean(dim=-1, keepdim=True) - xh * (g * xh).mean(dim=-1, keepdim=True))
+        return dx.to(gy.dtype), None
 
 
 class PCLayerNorm(nn.Module):
