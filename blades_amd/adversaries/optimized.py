@@ -192,3 +192,15 @@ class AttackclippedclusteringAdversary(Adversary):
                 alpha, beta = 10 * (ca / mean_norm + cb * alpha), 10 * cb * beta
                 theta = theta + theta_cross - 1e-4
             U[r] = alpha * mean + beta * x_far
+
+
+def find_orthogonal_unit_vector(v: torch.Tensor) -> torch.Tensor:
+    """A unit vector orthogonal to ``v`` (reference ``signguard_adversary.py:10-23`` keeps this helper although its
+    attack never calls it): Gram-Schmidt of a fixed pseudo-random direction against ``v``."""
+    v = v.reshape(-1).float()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    r = torch.randn(v.numel(), generator=g).to(v.device)
+    vv = torch.dot(v, v)
+    if float(vv) > 0:
+        r = r - torch.dot(r, v) / vv * v
+    return r / r.norm().clamp_min(1e-12)

@@ -78,6 +78,20 @@ def _cvt(size, patch, img_size, positional_embedding, num_classes, pretrained=Fa
     return CVT(num_layers=L, num_heads=H, mlp_ratio=R, embedding_dim=E, kernel_size=patch, **kw)
 
 
+def _cct_factory(size, kernel, n_conv, img, pe, classes):
+    def make(pretrained=False, progress=False, img_size=img, positional_embedding=pe, num_classes=classes, **kw):
+        return _cct(size, kernel, n_conv, img_size, positional_embedding, num_classes, pretrained, progress, **kw)
+
+    return make
+
+
+def _cvt_factory(size, patch, img, pe, classes):
+    def make(pretrained=False, progress=False, img_size=img, positional_embedding=pe, num_classes=classes, **kw):
+        return _cvt(size, patch, img_size, positional_embedding, num_classes, pretrained, progress, **kw)
+
+    return make
+
+
 _CCT_VARIANTS = [  # (size, kernel, conv layers, img, classes, suffixes)
     (2, 3, 2, 32, 10, ("", "_sine")), (4, 3, 2, 32, 10, ("", "_sine")), (6, 3, 1, 32, 10, ("", "_sine")),
     (6, 3, 2, 32, 10, ("", "_sine")), (7, 3, 1, 32, 10, ("", "_sine")), (7, 3, 2, 32, 10, ("", "_sine")),
@@ -87,14 +101,23 @@ __all__ = ["CCT", "CVT", "Tokenizer", "TransformerClassifier", "TransformerEncod
 for _s, _k, _n, _img, _nc, _sufs in _CCT_VARIANTS:
     for _suf in _sufs:
         _name = f"cct_{_s}_{_k}x{_n}_{_img}{_suf}"
-        globals()[_name] = partial(_cct, _s, _k, _n, _img, "sine" if _suf else "learnable", _nc)
+        globals()[_name] = _cct_factory(_s, _k, _n, _img, "sine" if _suf else "learnable", _nc)
+        globals()[_name].__name__ = _name
         __all__.append(_name)
-cct_7_3x1_32_c100 = partial(_cct, 7, 3, 1, 32, "learnable", 100)
-cct_7_3x1_32_sine_c100 = partial(_cct, 7, 3, 1, 32, "sine", 100)
-cct_14_7x2_384_fl = partial(_cct, 14, 7, 2, 384, "learnable", 102)
+cct_7_3x1_32_c100 = _cct_factory(7, 3, 1, 32, "learnable", 100)
+cct_7_3x1_32_sine_c100 = _cct_factory(7, 3, 1, 32, "sine", 100)
+cct_14_7x2_384_fl = _cct_factory(14, 7, 2, 384, "learnable", 102)
 __all__ += ["cct_7_3x1_32_c100", "cct_7_3x1_32_sine_c100", "cct_14_7x2_384_fl"]
 for _s in (2, 4, 6, 7):
     for _suf in ("", "_sine"):
         _name = f"cvt_{_s}_4_32{_suf}"
-        globals()[_name] = partial(_cvt, _s, 4, 32, "sine" if _suf else "learnable", 10)
+        globals()[_name] = _cvt_factory(_s, 4, 32, "sine" if _suf else "learnable", 10)
+        globals()[_name].__name__ = _name
         __all__.append(_name)
+
+from .helpers import fc_check, pe_check, resize_pos_embed  # noqa: E402,F401
+from .text import (Embedder, MaskedAttention, MaskedTransformerClassifier,  # noqa: E402,F401
+                   MaskedTransformerEncoderLayer, TextCCT, TextTokenizer)
+
+__all__ += ["Embedder", "TextTokenizer", "MaskedAttention", "MaskedTransformerEncoderLayer",
+            "MaskedTransformerClassifier", "TextCCT", "resize_pos_embed", "pe_check", "fc_check"]

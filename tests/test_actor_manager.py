@@ -142,3 +142,36 @@ def test_session_and_shims():
         S.get_session()
     S.init_session()
     assert isinstance(S.get_session(), S.FLSession)
+
+
+def _widx():
+    return int(os.environ["BLADES_WORKER_INDEX"])
+
+
+def test_process_worker_group_call_surface():
+    from fllib._internal.worker_group import WorkerGroup
+
+    with pytest.raises(ValueError):
+        WorkerGroup(0)
+    wg = WorkerGroup(2, env={"BLADES_TEST_FLAG": "7"})
+    try:
+        assert len(wg) == 2
+        assert wg.execute(_widx) == [0, 1]
+        assert wg.execute(lambda a, b=1: a * b + int(os.environ["BLADES_TEST_FLAG"]), 3, b=2) == [13, 13]
+        pids = wg.execute(os.getpid)
+        assert len(set(pids)) == 2 and os.getpid() not in pids
+        assert wg.execute_single(1, _widx) == 1
+        futs = wg.execute_async(lambda: "x")
+        assert [f.result(60) for f in futs] == ["x", "x"]
+        wg.add_workers(1)
+        assert wg.execute(_widx) == [0, 1, 2]
+        wg.remove_workers([0])
+        assert wg.execute(_widx) == [1, 2]
+        with pytest.raises(ValueError):
+            wg.execute_single(5, _widx)
+        with pytest.raises(ZeroDivisionError):
+            wg.execute(lambda: 1 // 0)
+    finally:
+        wg.shutdown()
+    with pytest.raises(RuntimeError):
+        wg.execute(_widx)

@@ -164,6 +164,42 @@ def test_cct_through_generic_engine(data_root):
     from tests.test_engine_paths import build
 
     a = build(data_root, "cct", "auto", K=3, bs=4)
-    assert a.engine.fused is None  # LayerNorm/attention -> generic vectorised path
+    assert a.engine.fused is not None  # shared-weight executor: per-client LayerNorm / embedding gradients
     r = a.train()
     assert np.isfinite(r["train_loss"]) and float(a.update_matrix.abs().sum()) > 0
+    b = build(data_root, "cct", "vmap", K=3, bs=4)  # the generic vectorised path still takes it
+    assert b.engine.fused is None
+    r = b.train()
+    assert np.isfinite(r["train_loss"]) and float(b.update_matrix.abs().sum()) > 0
+
+
+def test_text_transformer_variants_and_checkpoint_helpers():
+    """Masked (padding-aware) CCT pieces + positional-table resampling (reference: cctnets/utils/*)."""
+    import torch
+    from blades_amd.models import cctnets as C
+
+    torch.manual_seed(0)
+    m = C.TextCCT(seq_len=12, word_embedding_dim=16, embedding_dim=32, vocab_size=50, num_classes=3).eval()
+    ids = torch.randint(2, 50, (4, 12))
+    mask = torch.ones(4, 12, dtype=torch.bool)
+    mask[:, 8:] = False
+    out = m(ids, mask)
+    assert out.shape == (4, 3) and torch.isfinite(out).all()
+    # padded positions must not influence the result
+    ids2 = ids.clone()
+    ids2[:, 8:] = torch.randint(2, 50, (4, 4))
+    torch.testing.assert_close(m(ids2, mask), out)
+    out.sum().backward()
+    assert all(p.grad is not None for p in m.parameters() if p.requires_grad)
+    # class-token variant + learnable table
+    clf = C.MaskedTransformerClassifier(seq_pool=False, embedding_dim=32, num_layers=1, num_heads=2, mlp_ratio=1.0,
+                                        num_classes=5, positional_embedding="learnable", seq_len=6).eval()
+    assert clf(torch.randn(2, 6, 32), torch.ones(2, 6, dtype=torch.bool)).shape == (2, 5)
+    assert clf(torch.randn(2, 4, 32)).shape == (2, 5)  # short input is padded to the table
+    # positional table resampling 4x4 -> 8x8 grid, fc reset on class-count change
+    small, big = C.cct_2_3x2_32(img_size=16), C.cct_2_3x2_32(img_size=32, num_classes=7)
+    sd = {k: v.clone() for k, v in small.state_dict().items()}
+    sd = C.fc_check(big, C.pe_check(big, sd))
+    assert sd["classifier.positional_emb"].shape == big.state_dict()["classifier.positional_emb"].shape
+    assert sd["classifier.fc.weight"].shape[0] == 7
+    big.load_state_dict(sd)
