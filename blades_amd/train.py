@@ -66,7 +66,8 @@ def load_experiments_from_file(config_file: str, file_type: Optional[str] = None
 
 def run_fllib_experiments(experiments: dict, v: bool = False, vv: bool = False, resume: bool = False,
                           max_concurrent: Optional[int] = None, local_dir: Optional[str] = None,
-                          synthetic_data: bool = False, **ignored):
+                          synthetic_data: bool = False, scheduler: Optional[str] = None,
+                          scheduler_config: Optional[dict] = None, **ignored):
     if synthetic_data:
         os.environ["BLADES_SYNTHETIC_DATA"] = "1"
     for exp in experiments.values():
@@ -77,7 +78,14 @@ def run_fllib_experiments(experiments: dict, v: bool = False, vv: bool = False, 
     from blades_amd.parallel.runtime import init_runtime, shutdown_runtime
 
     init_runtime()
-    trials = run_experiments(experiments, resume=resume, verbose=2 if vv else 1, max_concurrent=max_concurrent)
+    sched = None
+    if scheduler and scheduler.lower() != "fifo":
+        from blades_amd.tune.schedulers import create_scheduler
+
+        sched = {"type": scheduler, **(scheduler_config or {})}
+        create_scheduler(scheduler, **(scheduler_config or {}))  # fail on a bad name / argument before any trial
+    trials = run_experiments(experiments, resume=resume, verbose=2 if vv else 1, max_concurrent=max_concurrent,
+                             scheduler=sched)
     shutdown_runtime()
     return trials
 
@@ -102,8 +110,9 @@ def file(
     ray_num_nodes: Optional[int] = typer.Option(None, "--ray-num-nodes", help="ignored"),
     ray_object_store_memory: Optional[int] = typer.Option(None, "--ray-object-store-memory", help="ignored"),
     resume: bool = typer.Option(False, "--resume", help="continue unfinished trials from their last checkpoint"),
-    scheduler: Optional[str] = typer.Option("FIFO", "--scheduler", help="only FIFO"),
-    scheduler_config: str = typer.Option("{}", "--scheduler-config", help="ignored"),
+    scheduler: Optional[str] = typer.Option("FIFO", "--scheduler", help="FIFO | median | asha (tune/schedulers.py)"),
+    scheduler_config: str = typer.Option("{}", "--scheduler-config",
+                                         help='scheduler arguments, e.g. \'{"metric": "acc_top_1", "max_t": 2000}\''),
     max_concurrent: Optional[int] = typer.Option(None, "--max-concurrent", help="trials in flight (default: #GPUs)"),
     local_dir: Optional[str] = typer.Option(None, "--local-dir", help="results root (default ~/blades_results)"),
     synthetic_data: bool = typer.Option(False, "--synthetic-data",
@@ -119,7 +128,8 @@ def file(
     experiments = load_experiments_from_file(config_file, None, stop, checkpoint_config)
     run_fllib_experiments(experiments, v=v, vv=vv, resume=resume,
                           max_concurrent=1 if local_mode else max_concurrent, local_dir=local_dir,
-                          synthetic_data=synthetic_data)
+                          synthetic_data=synthetic_data, scheduler=scheduler,
+                          scheduler_config=yaml.safe_load(scheduler_config) or {})
 
 
 @train_app.callback(invoke_without_command=True)

@@ -116,6 +116,11 @@ def run_trial(trial: Dict[str, Any], resume: bool = False, verbose: int = 1) -> 
     at_end = bool(ccfg.get("checkpoint_at_end", False))
     keep = ccfg.get("num_to_keep")
     stop = dict(trial.get("stop") or {})
+    from .schedulers import create_scheduler
+
+    sched_spec = dict(trial.get("scheduler") or {})
+    early = create_scheduler(sched_spec.pop("type", "FIFO"), **sched_spec)
+    exp_dir = os.path.join(trial["local_dir"], trial["experiment"])
     result: Dict[str, Any] = {}
     saved: List[str] = sorted(glob.glob(os.path.join(trial_dir, "checkpoint_*")))
 
@@ -142,6 +147,11 @@ def run_trial(trial: Dict[str, Any], resume: bool = False, verbose: int = 1) -> 
         if freq and algo.iteration % freq == 0:
             save()
         if should_stop(result, stop):
+            break
+        if early.should_stop(exp_dir, trial["dir_name"], result):  # file-based: every rank reads the same rows
+            if verbose and rt.is_main:
+                print(f"[{trial['dir_name'][:60]}] stopped early by {type(early).__name__} at iteration "
+                      f"{algo.iteration}", flush=True)
             break
     if at_end:
         save()
@@ -220,6 +230,10 @@ def run_experiments(experiments: Dict[str, Dict[str, Any]], resume: bool = False
     trials: List[Dict[str, Any]] = []
     for name, spec in experiments.items():
         trials.extend(make_trials(name, spec))
+    if scheduler:  # {"type": "asha", ...} or a name; travels to the trial processes inside the trial descriptor
+        sched = {"type": scheduler} if isinstance(scheduler, str) else dict(scheduler)
+        for t in trials:
+            t["scheduler"] = sched
     rt = get_runtime()
     if in_process is None:
         in_process = rt.distributed or not concurrent or max_concurrent == 1 or len(trials) == 1

@@ -101,3 +101,38 @@ def test_stop_on_metric_threshold():
     assert should_stop({"train_loss": 1e6}, {"train_loss": 100000})
     assert not should_stop({"train_loss": 2.0}, {"train_loss": 100000, "training_iteration": 10})
     assert should_stop({"train_loss": float("nan")}, {"train_loss": 100000})
+
+
+def test_early_stopping_schedulers(tmp_path):
+    """File-based MedianStoppingRule / ASHA (tune/schedulers.py): decisions from the trials' result.json files."""
+    import json
+    from blades_amd.tune.schedulers import create_scheduler
+
+    exp = tmp_path / "exp"
+
+    def write(name, accs, every=10):
+        d = exp / name
+        d.mkdir(parents=True)
+        with open(d / "result.json", "w") as f:
+            for i, a in enumerate(accs):
+                f.write(json.dumps({"training_iteration": (i + 1) * every, "acc_top_1": a, "train_loss": 1 - a}) + "\n")
+
+    write("good_a", [0.5, 0.7, 0.8, 0.85])
+    write("good_b", [0.4, 0.6, 0.75, 0.8])
+    write("good_c", [0.45, 0.65, 0.7, 0.82])
+    write("mine", [0.48])
+    assert not create_scheduler("FIFO").should_stop(str(exp), "mine", {"training_iteration": 20, "acc_top_1": 0.1})
+    med = create_scheduler("median", metric="acc_top_1", mode="max", grace_period=10, min_samples_required=3)
+    assert med.should_stop(str(exp), "mine", {"training_iteration": 20, "acc_top_1": 0.12})
+    assert not med.should_stop(str(exp), "mine", {"training_iteration": 20, "acc_top_1": 0.9})
+    assert not med.should_stop(str(exp), "mine", {"training_iteration": 20, "train_loss": 3.0})  # not an eval round
+    lossy = create_scheduler("median", metric="train_loss", mode="min", min_samples_required=3)
+    assert lossy.should_stop(str(exp), "mine", {"training_iteration": 20, "train_loss": 0.95})
+    assert not lossy.should_stop(str(exp), "mine", {"training_iteration": 20, "train_loss": 0.05})
+    asha = create_scheduler("asha", metric="acc_top_1", mode="max", max_t=40, grace_period=10, reduction_factor=2)
+    assert asha.rungs == [10, 20]
+    assert asha.should_stop(str(exp), "mine", {"training_iteration": 20, "acc_top_1": 0.2})       # bottom half
+    assert not asha.should_stop(str(exp), "mine", {"training_iteration": 20, "acc_top_1": 0.72})  # top half
+    assert asha.should_stop(str(exp), "mine", {"training_iteration": 40, "acc_top_1": 0.99})      # budget reached
+    with pytest.raises(ValueError):
+        create_scheduler("pbt")
