@@ -1,5 +1,4 @@
 """ALIE, IPM, Noise, SignFlip, LabelFlip adversaries."""
-import math
 from typing import Dict, Optional
 
 import torch

@@ -11,7 +11,7 @@ mean "use the GPU".
 """
 import copy
 import logging
-from typing import Callable, Optional, Union
+from typing import Callable, Optional
 
 from blades_amd.clients import ClientConfig
 from blades_amd.parallel.worker_group_config import WorkerGroupConfig

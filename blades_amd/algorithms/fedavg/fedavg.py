@@ -33,7 +33,7 @@ from blades_amd.constants import CLIENT_UPDATE, NUM_GLOBAL_STEPS
 from blades_amd.datasets.catalog import DatasetCatalog
 from blades_amd.engine.trainer import ClientEngine
 from blades_amd.parallel.runtime import get_runtime
-from blades_amd.parallel.worker_group_config import WorkerGroupConfig
+from blades_amd.parallel.worker_group_config import WorkerGroupConfig  # noqa: F401  (re-exported like the reference module)
 from blades_amd.types import NotProvided
 from blades_amd.utils.from_config import deep_update
 from blades_amd.utils.timers import PhaseTimers

@@ -10,7 +10,7 @@ parameters are views into it) and the step is the fused kernel
 all-gather of the slices (identity on one rank).  The optimizer ``type`` key is
 ignored like in the reference — it is always SGD.
 """
-from typing import Dict, List, Optional, Sequence, Union
+from typing import Dict, Optional, Sequence, Union
 
 import torch
 import torch.distributed as dist

@@ -1,7 +1,7 @@
 """Client configuration (fields/defaults of ``fllib/clients/client_config.py:22-233``)."""
 import copy
 import logging
-from typing import Callable, Dict, Optional
+from typing import Callable, Dict
 
 from blades_amd.types import NotProvided, PartialAlgorithmConfigDict
 from blades_amd.utils.from_config import from_config, log_once

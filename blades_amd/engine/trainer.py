@@ -462,11 +462,14 @@ class ClientEngine:
         seq = [k for k, r in enumerate(self._train_rows) if self._specs[r] is None]
         nontrain = [r for r in range(self.Kloc) if not self._trains[r]]
         if nontrain:
-            key = (b"n", self._spec_version)
-            nt = self._row_vec_cache.get(key)
-            if nt is None:
-                nt = self._row_vec_cache[key] = torch.as_tensor(nontrain, device=dev)
-            self.U_row[nt] = 0
+            if nontrain[-1] - nontrain[0] == len(nontrain) - 1:
+                self.U_row[nontrain[0]: nontrain[-1] + 1].zero_()  # one memset instead of an index_put
+            else:
+                key = (b"n", self._spec_version)
+                nt = self._row_vec_cache.get(key)
+                if nt is None:
+                    nt = self._row_vec_cache[key] = torch.as_tensor(nontrain, device=dev)
+                self.U_row[nt] = 0
         # rows whose content is final only at the end of the round (sequential clients, round-end hooks):
         # with any of those the exchange cannot start early
         late = bool(seq) or self._has_round_end_hooks()

@@ -8,7 +8,6 @@ layout (``tokenizer.conv_layers.N.0``, ``classifier.blocks.N.{pre_norm,self_attn
 self_attn.proj,linear1,norm1,linear2}``, ``classifier.{positional_emb,attention_pool,norm,fc}``)
 so the flattened parameter order — and therefore update vectors — line up with the reference's.
 """
-import math
 
 import torch
 import torch.nn.functional as F

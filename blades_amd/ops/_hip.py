@@ -10,7 +10,7 @@ Importing this module without the built library raises — GPU tensors never
 fall back to a PyTorch implementation.
 """
 import ctypes
-from ctypes import c_float, c_int, c_long, c_longlong, c_uint, c_ulonglong, c_void_p
+from ctypes import c_float, c_int, c_long, c_uint, c_ulonglong, c_void_p
 from typing import Optional
 
 import torch

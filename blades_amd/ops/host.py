@@ -1,6 +1,5 @@
 """ctypes bindings of ``libblades_host.so`` (built on demand with g++)."""
 import ctypes
-from typing import Optional
 
 import numpy as np
 

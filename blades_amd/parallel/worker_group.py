@@ -9,7 +9,7 @@ actors — one process per GPU, the client→rank map is static
 the reference fans out to remote actors run on the local worker; cross-rank
 data movement is done by the engine with RCCL collectives, not through here.
 """
-from typing import Any, Callable, List, Optional, Sequence
+from typing import Any, Callable, List, Sequence
 
 from .scaling_config import WorkerGroupScalingConfig
 from .worker import Worker, WorkerSpec

@@ -8,7 +8,7 @@ routine instead of torchmetrics.
 """
 import copy
 import threading
-from typing import Callable, Dict, List, Optional, Union
+from typing import Callable, Dict, List, Optional
 
 import numpy as np
 import torch

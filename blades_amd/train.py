@@ -11,7 +11,6 @@ multi-GPU *single* trial is started with ``torch.distributed.run``::
 import importlib.util
 import json
 import os
-import sys
 from typing import Optional
 
 import typer

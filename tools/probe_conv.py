@@ -2,7 +2,7 @@
 
 Run on the GPU box: python tools/probe_conv.py > gpurun_out/probe_conv.log
 """
-import sys, time, torch
+import time, torch
 import torch.nn.functional as F
 
 dev = "cuda"

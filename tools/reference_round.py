@@ -12,7 +12,6 @@ usage: python tools/reference_round.py [--clients 1000] [--rounds 2] [--model re
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
