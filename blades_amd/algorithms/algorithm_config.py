@@ -63,7 +63,7 @@ class AlgorithmConfig:
 
         # MI355X engine knobs
         self.execution_mode = "auto"
-        self.clients_per_chunk = 64
+        self.clients_per_chunk = "auto"  # int, or "auto" (engine/trainer.py picks per device and batch size)
         self.amp_dtype = "auto"
         self.device = "auto"
         self.nan_guard = True
