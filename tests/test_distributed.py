@@ -55,6 +55,18 @@ def test_world_size_invariance(tmp_path, agg, adv):
         assert abs(got["acc"] - ref["acc"]) < 1e-6
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_world_sizes_4_and_8(tmp_path, world):
+    """The rank counts the node is actually run with (world sizes 1/2/4/8): 18 clients, 4 of
+    them forging, so shards are uneven and — at 8 ranks — some ranks hold no attacker at all."""
+    spec = {"K": 18, "f": 4, "agg": {"type": "Trimmedmean"}, "adv": {"type": "blades.adversaries.ALIEAdversary"},
+            "rounds": 2, "root": str(tmp_path), "smom": 0.9}
+    ref = run(1, spec, str(tmp_path / "w1.pt"))
+    got = run(world, spec, str(tmp_path / f"w{world}.pt"))
+    torch.testing.assert_close(got["theta"], ref["theta"], rtol=1e-3, atol=1e-4)
+    assert abs(got["train_loss"] - ref["train_loss"]) < 1e-4
+
+
 def test_multi_batch_general_path_two_ranks(tmp_path):
     spec = {"K": 6, "f": 1, "agg": {"type": "Median"}, "adv": {"type": "blades.adversaries.ALIEAdversary"},
             "rounds": 2, "root": str(tmp_path), "nb": 3}
