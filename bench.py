@@ -39,7 +39,9 @@ def main():
     ap.add_argument("--aggregator", default="Median")
     ap.add_argument("--adversary", default="ALIEAdversary")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=200, help="clients vectorised per kernel chunk")
+    ap.add_argument("--chunk", type=int, default=400,
+                    help="clients vectorised per kernel chunk (400 x 64 samples: 102 GB peak HBM on ResNet-18, +3 %% "
+                         "over 200; multi-GPU runs use at most half a rank's clients so the exchange overlaps)")
     ap.add_argument("--amp", default="bf16")
     ap.add_argument("--samples-per-client", type=int, default=128)
     ap.add_argument("--local-steps", type=int, default=1, help="client SGD steps per round (1 = FedSGD headline)")
@@ -156,6 +158,8 @@ def main():
             "samples_per_sec": round(value * (K - f) * args.batch, 1),
             "phase_ms": {k: round(v, 3) for k, v in timers.items()},
             "train_loss": last.get("train_loss") if last else None,
+            "clients_per_chunk": algo.engine.chunk,
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if rt.device.type == "cuda" else None,
         }
         # BASELINE.md publishes no throughput.  For context only: tools/reference_round.py (a sequential
         # per-client plain-PyTorch fp32 restatement of the reference round, no Ray overhead) measured

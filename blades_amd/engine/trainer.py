@@ -115,6 +115,12 @@ class ClientEngine:
         # ---- resident data
         ids = [clients[i].client_id for i in self.local_ids]
         self._train_rows = np.array([r for r, i in enumerate(self.local_ids) if self._trains[r]], dtype=np.int64)
+        if G > 1:
+            # at least two chunks per rank: the all-to-all piece of the first travels while the second trains
+            # (all ranks must agree on the piece count, so the rule uses the largest per-rank training load)
+            most = max(sum(1 for c in rc if trains[c]) for rc in self.plan.rank_clients)
+            if most >= 2:
+                self.chunk = max(1, min(self.chunk, -(-most // 2)))
         train_ids = [ids[r] for r in self._train_rows]
         self.train_store = dataset.device_store(train_ids, self.device, "train")
         self._train_uids = np.array([self.local_ids[r] for r in self._train_rows], dtype=np.int64)
@@ -409,7 +415,7 @@ class ClientEngine:
     def _train_chunk_general(self, theta, rows, srows):
         gscale0, flip, gclip = self._row_vectors(rows)
         Kc = len(rows)
-        W = theta.unsqueeze(0).expand(Kc, self.D).contiguous()
+        W = theta.unsqueeze(0).repeat(Kc, 1)  # a real copy even for Kc == 1 (expand().contiguous() would alias theta)
         G = torch.empty_like(W)
         srows_t = torch.as_tensor(srows, device=self.device)
         if self.momentum != 0.0:

@@ -119,3 +119,26 @@ def test_dgrad_as_forward_conv_matches_autograd():
         gy = torch.randn(y.shape, generator=g)
         (ref,) = torch.autograd.grad(y, x, gy)
         torch.testing.assert_close(dgrad_same_conv(gy, w, (k // 2, k // 2)), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["fused", "vmap"])
+def test_local_steps_do_not_depend_on_chunking(data_root, mode):
+    """Updates of the multi-step path must not depend on how clients are cut into chunks — in particular a chunk
+    holding a single client (regression: its weight replica used to alias the global weights)."""
+    def run(chunk):
+        a = build(data_root, "mlp", mode, "fashionmnist", nb=3, K=5)
+        a.engine.chunk = chunk
+        for net in (a.engine.task.model, a.engine.model, a.engine.grouped.template if a.engine.grouped else None):
+            if net is not None:
+                _no_random_drops(net)
+        theta0 = a.server.theta.clone()
+        U, _ = one_round_updates(a)
+        return U, theta0
+
+    U3, t3 = run(3)
+    U2, t2 = run(2)   # chunks of 2, 2 and 1 clients
+    U1, _ = run(1)
+    torch.testing.assert_close(t3, t2)
+    torch.testing.assert_close(U2, U3, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(U1, U3, rtol=1e-5, atol=1e-6)
+    assert float(U1.abs().sum(1).min()) > 0
