@@ -74,3 +74,42 @@ def test_auto_mode_picks_graphs_only_for_small_rounds(tmp_path):
     eng.D_saved, eng.D = eng.D, 10 ** 12  # pretend the model is huge
     assert not eng._graphs_wanted()
     eng.D = eng.D_saved
+
+
+def test_two_chunk_streams_match_one(tmp_path):
+    """Chunks alternating over two HIP streams (the single-GPU default) must give the rows a single stream gives."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from blades_amd.algorithms.fedavg import FedavgConfig
+
+    def run(streams):
+        os.environ["BLADES_CHUNK_STREAMS"] = str(streams)
+        os.environ["BLADES_HIP_GRAPH"] = "0"
+        os.environ["BLADES_SYNTHETIC_DATA"] = "1"
+        try:
+            cfg = (FedavgConfig().resources(num_gpus_for_driver=1)
+                   .data(dataset_config={"type": "cifar10", "num_clients": 10, "num_classes": 10,
+                                         "train_batch_size": 8, "n_train": 400, "n_test": 80,
+                                         "data_root": str(tmp_path), "use_cache": False})
+                   .training(global_model="resnet", server_config={"aggregator": {"type": "Median"},
+                                                                   "optimizer": {"lr": 0.0}})
+                   .client(client_config={"lr": 1.0})
+                   .adversary(num_malicious_clients=2,
+                              adversary_config={"type": "blades.adversaries.ALIEAdversary"})
+                   .evaluation(evaluation_interval=0)
+                   .engine(clients_per_chunk=3))
+            cfg.seed = 9
+            algo = cfg.build()
+            assert algo.engine.n_streams == streams
+            losses = [algo.train()["train_loss"] for _ in range(3)]
+            torch.cuda.synchronize()
+            return algo.update_matrix[:, : algo.engine.D].clone(), losses
+        finally:
+            os.environ.pop("BLADES_CHUNK_STREAMS", None)
+            os.environ.pop("BLADES_HIP_GRAPH", None)
+
+    U1, l1 = run(1)
+    U2, l2 = run(2)
+    assert max(abs(a - b) for a, b in zip(l1, l2)) < 2e-3, (l1, l2)
+    cos = torch.nn.functional.cosine_similarity(U1, U2, dim=1)
+    assert float(cos.min()) > 0.99, cos
