@@ -361,7 +361,8 @@ class ClientEngine:
                 self._chunk_graphs.clear()
                 torch.cuda.synchronize()
                 return None
-            ent.update(graph=g, losses=losses, params=params)
+            # everything the graph reads by address must outlive it: keep the per-chunk tensors with the graph
+            ent.update(graph=g, losses=losses, params=params, keep=(scale, flip, gscale, block, dev_rows))
         self.sampler.prepare(srows)
         if aug:
             table = tf.draw(Kc, None, store_hw(self.train_store)[0], store_hw(self.train_store)[1],
@@ -494,6 +495,8 @@ class ClientEngine:
         # Optional: chunks alternate between `n_streams` HIP streams so that one chunk's memory-bound kernels
         # (per-client BN, elementwise) can overlap another chunk's MFMA-bound convolutions.
         n_streams = self.n_streams if (dev.type == "cuda" and not late) else 1
+        if n_streams > 1 and self._graphs_wanted():
+            n_streams = 1  # chunk graphs share one memory pool, which is only valid for replays in sequence
         streams = self._chunk_streams(n_streams)
         pending = []
         with torch.enable_grad():

@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2, server_lr=0.0):
+def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2, server_lr=0.0, chunk="auto"):
     from blades_amd.algorithms.fedavg import FedavgConfig
 
     old = os.environ.get("BLADES_HIP_GRAPH")
@@ -22,7 +22,8 @@ def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2, server_lr=0.0):
                                                             "optimizer": {"lr": server_lr, "momentum": 0.0}})
                .client(client_config={"lr": 1.0})
                .adversary(num_malicious_clients=f, adversary_config={"type": f"blades.adversaries.{adv}"})
-               .evaluation(evaluation_interval=0))
+               .evaluation(evaluation_interval=0)
+               .engine(clients_per_chunk=chunk))
         cfg.seed = 5
         algo = cfg.build()
         losses = [algo.train()["train_loss"] for _ in range(rounds)]
@@ -36,16 +37,17 @@ def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2, server_lr=0.0):
             os.environ["BLADES_HIP_GRAPH"] = old
 
 
-@pytest.mark.parametrize("ds,model,adv", [("cifar10", "resnet", "ALIEAdversary"),
-                                          ("fashionmnist", "cnn", "LabelFlipAdversary"),
-                                          ("cifar10", "resnet", "SignFlipAdversary")])
-def test_graph_replay_matches_eager_bitwise(tmp_path, ds, model, adv):
+@pytest.mark.parametrize("ds,model,adv,chunk", [("cifar10", "resnet", "ALIEAdversary", "auto"),
+                                                ("fashionmnist", "cnn", "LabelFlipAdversary", "auto"),
+                                                ("cifar10", "resnet", "SignFlipAdversary", "auto"),
+                                                ("cifar10", "resnet", "ALIEAdversary", 2)])  # three chunk graphs
+def test_graph_replay_matches_eager_bitwise(tmp_path, ds, model, adv, chunk):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     # 20 samples per client, batch 8: the epoch ends every other round, so reshuffles happen between replays
-    th_e, loss_e, eng_e = _run(tmp_path, "0", ds, model, adv)
-    th_e2, loss_e2, _ = _run(tmp_path, "0", ds, model, adv)
-    th_g, loss_g, eng_g = _run(tmp_path, "1", ds, model, adv)
+    th_e, loss_e, eng_e = _run(tmp_path, "0", ds, model, adv, chunk=chunk)
+    th_e2, loss_e2, _ = _run(tmp_path, "0", ds, model, adv, chunk=chunk)
+    th_g, loss_g, eng_g = _run(tmp_path, "1", ds, model, adv, chunk=chunk)
     assert eng_e.graph_replays == 0
     assert eng_g.graph_replays >= 4, getattr(eng_g, "_graph_error", None)
     assert all(l == l for l in loss_g) and torch.isfinite(th_g).all()
