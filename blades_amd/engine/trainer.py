@@ -560,8 +560,13 @@ class ClientEngine:
         rows = self._round_end_rows()
         if not rows:
             return
-        rt = torch.as_tensor(rows, device=self.device)
-        blk = self.U_row[rt][:, : self.D].contiguous()
+        rows = [int(r) for r in rows]
+        inplace = rows[-1] - rows[0] == len(rows) - 1  # consecutive rows: work on the matrix itself, no copies
+        if inplace:
+            blk = self.U_row[rows[0]: rows[-1] + 1, : self.D]
+        else:
+            rt = torch.as_tensor(rows, device=self.device)
+            blk = self.U_row[rt][:, : self.D].contiguous()
         clips = [self._specs[r].get("update_clip", float("inf")) for r in rows]
         clip = torch.tensor(clips, device=self.device)
         if any(np.isfinite(c) for c in clips):
@@ -572,7 +577,8 @@ class ClientEngine:
                 sel = [k for k, r in enumerate(rows) if self._specs[r].get("update_noise_std", 0.0) == std]
                 pairs = torch.tensor([[k, self.local_ids[rows[k]]] for k in sel], dtype=torch.int64)
                 ops.add_normal_rows_(blk, pairs, self.seed, 1000 + self.round, 0, self.D, 0.0, std, False)
-        self.U_row[rt, : self.D] = blk
+        if not inplace:
+            self.U_row[rt, : self.D] = blk
 
     # ------------------------------------------------------------------
     def exchange(self) -> torch.Tensor:

@@ -1,4 +1,5 @@
-"""HIP-graph replay of a FedSGD chunk must reproduce the eager path (same kernels, same order => same bits)."""
+"""Engine execution variants on the GPU: HIP-graph replay and multi-stream chunks must reproduce the eager single-stream
+path; FEDAVG_DP round-end hooks on the row-strided update matrix."""
 import os
 
 import pytest
@@ -115,3 +116,35 @@ def test_two_chunk_streams_match_one(tmp_path):
     assert max(abs(a - b) for a, b in zip(l1, l2)) < 2e-3, (l1, l2)
     cos = torch.nn.functional.cosine_similarity(U1, U2, dim=1)
     assert float(cos.min()) > 0.99, cos
+
+
+def test_dp_fedavg_round_on_gpu(tmp_path):
+    """FEDAVG_DP on the GPU: round-end clip + noise run in place on the (row-strided) update matrix."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from blades_amd.algorithms.fedavg import FedavgDPConfig
+
+    os.environ["BLADES_SYNTHETIC_DATA"] = "1"
+
+    def build(eps, clip):
+        cfg = FedavgDPConfig().update_from_dict({
+            "dataset_config": {"type": "fashionmnist", "num_clients": 6, "num_classes": 10, "train_batch_size": 8,
+                               "train_bs": 8, "n_train": 96, "n_test": 24, "data_root": str(tmp_path),
+                               "use_cache": False},
+            "global_model": "cnn", "num_gpus_for_driver": 1, "evaluation_interval": 0, "seed": 3,
+            "client_config": {"lr": 1.0}, "server_config": {"aggregator": {"type": "Mean"}, "optimizer": {"lr": 0.1}},
+            "num_malicious_clients": 0, "dp_privacy_epsilon": eps})
+        cfg.dp_clip_threshold = clip
+        return cfg.build()
+
+    a = build(1e9, 0.05)  # ~no noise: isolates the clip
+    a.train()
+    norms = a.update_matrix[:, : a.engine.D].norm(dim=1)
+    assert float(norms.max()) <= 0.05 * 1.001 and float(norms.min()) > 0.04, norms
+    b = build(0.01, 0.05)  # huge noise
+    b.train()
+    nb = b.update_matrix[:, : b.engine.D].norm(dim=1)
+    assert torch.isfinite(nb).all() and float(nb.min()) > 1.0, nb
+    # noise is keyed by (seed, round, client): two clients never share it
+    U = b.update_matrix[:, : b.engine.D]
+    assert float(torch.nn.functional.cosine_similarity(U[0], U[1], dim=0).abs()) < 0.1
