@@ -304,6 +304,11 @@ class ClientEngine:
             return False
         if self.device.type != "cuda" or self.fused is None or self.nb != 1 or self.momentum != 0.0:
             return False
+        if getattr(self, "_round_chunks", 1) != 1:
+            # Only rounds that are one chunk are replayed.  Several chunk graphs sharing a memory pool produced
+            # sporadic non-finite rows on the GPU (not reproducible with the eager kernels, scratch poisoned or
+            # not); launch-bound rounds are single-chunk anyway, so multi-chunk rounds simply stay eager.
+            return False
         if self.hip_graphs in ("1", "on", "true"):
             return True
         # auto: per-round work small enough that launches dominate (ResNet-10 x 60 clients yes, the 1000-client
@@ -491,6 +496,7 @@ class ClientEngine:
         # rows whose content is final only at the end of the round (sequential clients, round-end hooks):
         # with any of those the exchange cannot start early
         late = bool(seq) or self._has_round_end_hooks()
+        self._round_chunks = -(-len(batched) // self.chunk) if batched else 0
         self._exchange_begin()
         # Optional: chunks alternate between `n_streams` HIP streams so that one chunk's memory-bound kernels
         # (per-client BN, elementwise) can overlap another chunk's MFMA-bound convolutions.
