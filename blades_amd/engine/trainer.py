@@ -146,7 +146,6 @@ class ClientEngine:
         # HIP-graph capture of a FedSGD chunk (see _graphed_chunk): "auto" turns it on for launch-bound rounds
         self.hip_graphs = os.environ.get("BLADES_HIP_GRAPH", "auto").lower()
         self._chunk_graphs = {}
-        self._graph_pool = None
         self._graph_failed = False
         self.graph_replays = 0
         self._streams = None
@@ -304,11 +303,6 @@ class ClientEngine:
             return False
         if self.device.type != "cuda" or self.fused is None or self.nb != 1 or self.momentum != 0.0:
             return False
-        if getattr(self, "_round_chunks", 1) != 1:
-            # Only rounds that are one chunk are replayed.  Several chunk graphs sharing a memory pool produced
-            # sporadic non-finite rows on the GPU (not reproducible with the eager kernels, scratch poisoned or
-            # not); launch-bound rounds are single-chunk anyway, so multi-chunk rounds simply stay eager.
-            return False
         if self.hip_graphs in ("1", "on", "true"):
             return True
         # auto: per-round work small enough that launches dominate (ResNet-10 x 60 clients yes, the 1000-client
@@ -354,11 +348,11 @@ class ClientEngine:
                     Y = torch.where(flip.unsqueeze(1) > 0, flip.unsqueeze(1) - 1 - Y, Y)
                 return self.fused.run(X, Y, block, scale)
 
-            if self._graph_pool is None:
-                self._graph_pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g, pool=self._graph_pool):
+                # every chunk graph gets a memory pool of its own: graphs sharing one pool produced sporadic
+                # non-finite rows in multi-chunk rounds; launch-bound rounds are small, so the memory is too
+                with torch.cuda.graph(g):
                     losses = body()
             except Exception as e:  # noqa: BLE001 — anything not capturable: stay eager for good
                 self._graph_failed = True
@@ -496,13 +490,12 @@ class ClientEngine:
         # rows whose content is final only at the end of the round (sequential clients, round-end hooks):
         # with any of those the exchange cannot start early
         late = bool(seq) or self._has_round_end_hooks()
-        self._round_chunks = -(-len(batched) // self.chunk) if batched else 0
         self._exchange_begin()
         # Optional: chunks alternate between `n_streams` HIP streams so that one chunk's memory-bound kernels
         # (per-client BN, elementwise) can overlap another chunk's MFMA-bound convolutions.
         n_streams = self.n_streams if (dev.type == "cuda" and not late) else 1
         if n_streams > 1 and self._graphs_wanted():
-            n_streams = 1  # chunk graphs share one memory pool, which is only valid for replays in sequence
+            n_streams = 1  # launch-bound rounds gain nothing from a second stream; keep replays in sequence
         streams = self._chunk_streams(n_streams)
         pending = []
         with torch.enable_grad():
