@@ -584,6 +584,81 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
 
 
 # ---------------------------------------------------------------------------
+# shared-weight convolution: forward and data gradient (ops/csrc/conv_igemm.hip)
+_conv_igemm_ws = _sig("blades_conv_igemm_ws", [c_int] * 6, c_long)
+_conv_igemm = _sig("blades_conv_igemm", [_P, _P, _P, _P, _P] + [c_int] * 13 + [_P], c_int)
+
+#: operand planes per compute dtype: fp32 tensors are split exactly into 3 bf16 planes (6 MFMA products, fp32
+#: grade), "bf16x3" keeps 2 planes (3 products, ~2^-17), bf16 tensors run as they are
+CONV_PLANES = {"fp32": 3, "bf16x3": 2, "bf16": 1}
+
+
+def _chk_nhwc(t: torch.Tensor, name: str, dtype):
+    if not (t.is_cuda and t.dtype == dtype and t.dim() == 4):
+        raise ValueError(f"{name}: expected a CUDA {dtype} 4-D tensor, got {t.dtype} {tuple(t.shape)}")
+    N, C, H, W = t.shape
+    if t.numel() and t.stride() != (H * W * C, 1, W * C, C) and not (
+            t.is_contiguous(memory_format=torch.channels_last) and (C == 1 or H * W == 1)):
+        raise ValueError(f"{name}: expected channels-last strides, got {t.stride()} for shape {tuple(t.shape)}")
+
+
+def conv_igemm_supported(x: torch.Tensor, weight: torch.Tensor, stride, pad, dilation, npl: int) -> bool:
+    want = torch.bfloat16 if npl == 1 else torch.float32
+    kh, kw = weight.shape[2:]
+    return (x.is_cuda and x.dtype == want and x.dim() == 4 and weight.dtype == torch.float32
+            and stride[0] == stride[1] and pad[0] == pad[1] and tuple(dilation) == (1, 1) and kh * kw <= 25
+            and x.shape[3] + 2 * pad[1] >= kw and x.shape[3] <= 256)
+
+
+def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, mode, npl):
+    w = weight.detach()
+    if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (Co, Ci, kh, kw)):
+        raise ValueError("conv_igemm: weight must be a contiguous CUDA fp32 [Co, Ci, kh, kw] tensor")
+    if bias is not None:
+        bias = _vec(bias.detach(), Co, inp.device, name="bias")
+    ws = torch.empty(_conv_igemm_ws(Co, Ci, kh, kw, mode, npl), dtype=torch.uint8, device=inp.device)
+    rc = _conv_igemm(_ptr(inp), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad,
+                     mode, npl, _stream())
+    if rc != 0:
+        raise ValueError(f"conv_igemm: unsupported configuration (rc={rc}): N={N} H={H} W={W} Ci={Ci} Co={Co} "
+                         f"k={kh}x{kw} stride={stride} pad={pad} mode={mode} npl={npl}")
+
+
+def conv_forward(x, weight, bias, stride: int, pad: int, npl: int):
+    """y = conv2d(x, weight, bias) for channels-last x; fp32 (npl 3 / 2) or bf16 (npl 1) in and out."""
+    dt = torch.bfloat16 if npl == 1 else torch.float32
+    _chk_nhwc(x, "x", dt)
+    N, Ci, H, W = x.shape
+    Co, Ci2, kh, kw = weight.shape
+    if Ci2 != Ci:
+        raise ValueError("conv_forward: channel mismatch")
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if Ho < 1 or Wo < 1:
+        raise ValueError("conv_forward: empty output")
+    y = torch.empty((N, Co, Ho, Wo), dtype=dt, device=x.device, memory_format=torch.channels_last)
+    if Co == 1 or Ho * Wo == 1:
+        y = y.as_strided(y.shape, (Ho * Wo * Co, 1, Wo * Co, Co))
+    _conv_call(x, weight, bias, y, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 0, npl)
+    return y
+
+
+def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int):
+    """dx of conv2d(x, weight) given gy (channels-last); ``in_hw`` = (H, W) of x."""
+    dt = torch.bfloat16 if npl == 1 else torch.float32
+    _chk_nhwc(gy, "gy", dt)
+    N, Co, Ho, Wo = gy.shape
+    Co2, Ci, kh, kw = weight.shape
+    H, W = in_hw
+    if Co2 != Co or Ho != (H + 2 * pad - kh) // stride + 1 or Wo != (W + 2 * pad - kw) // stride + 1:
+        raise ValueError("conv_dgrad: gy does not match the convolution geometry")
+    dx = torch.empty((N, Ci, H, W), dtype=dt, device=gy.device, memory_format=torch.channels_last)
+    if Ci == 1 or H * W == 1:
+        dx = dx.as_strided(dx.shape, (H * W * Ci, 1, W * Ci, Ci))
+    _conv_call(gy, weight, None, dx, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 1, npl)
+    return dx
+
+
+# ---------------------------------------------------------------------------
 # fused evaluation metrics
 _ce_topk = _sig("blades_ce_topk", [_P, c_long, _P, c_long, c_int, _P, c_int, _P, c_int, _P, _P], c_int)
 _ks_cache = {}

@@ -1,0 +1,515 @@
+// Shared-weight convolution (forward and data gradient) as an implicit GEMM on the bf16 matrix cores, with an
+// fp32-faithful operand split.
+//
+//   out[n, sy*so+poy, sx*so+pox, co] = bias[co] + sum_t sum_ci in[n, sy*si+ay_t, sx*si+ax_t, ci] * W_t[co][ci]
+//
+// One "tap table" form covers every convolution of the FedSGD fast path (reference hot loop: Task.train_one_batch,
+// fllib/tasks/task.py:170-186, which runs them through cuDNN):
+//   * forward, any stride/padding:       si = stride, so = 1, taps = all (r, s), ay = r - pad, ax = s - pad
+//   * data gradient, stride 1:           in = gy, taps (r, s) -> ay = pad - r, ax = pad - s, W transposed
+//   * data gradient, stride s > 1:       one launch per output parity class (ph, pw): so = s, taps = the (r, s)
+//                                        with (ph + pad - r) % s == 0, ay = (ph + pad - r) / s   (no zero-stuffing)
+// Activations are channels-last.  gfx950 has no TF32/xf32 path and its fp32 MFMA runs at 1/16 of the bf16 rate,
+// so fp32 operands are split *exactly* into NPL bf16 planes while they are staged into LDS
+// (x = h + m + l, 3 x 8 = 24 significant bits) and the product is evaluated as
+//   NPL = 3:  hh + hm + mh + hl + lh + mm   (6 MFMAs, dropped terms <= 2^-26 |a||b|: below one fp32 rounding)
+//   NPL = 2:  hh + hm + mh                  (3 MFMAs, ~2^-17 relative — "bf16x3", 64x tighter than TF32)
+//   NPL = 1:  plain bf16 in / bf16 out
+// always accumulating in fp32.  6 MFMAs per staged fragment pair also halve the LDS traffic per MFMA, so the
+// kernel is MFMA-bound by construction.
+//
+// CDNA4 mapping
+//   * workgroup = 4 waves = 64*MF output pixels x 64 output channels; wave w owns pixels [w*16*MF, (w+1)*16*MF)
+//     as MF fragments of v_mfma_f32_16x16x32_bf16 with the *weights* as the A operand, so a lane ends up with 4
+//     consecutive output channels of one pixel (16-byte channels-last stores).
+//   * K-step = (tap, 32 input channels).  The input tile is staged ONCE per 32-channel chunk as the tile's
+//     receptive field (rows x full width, zero halo shared between neighbouring rows / images) and every tap is
+//     just a different LDS offset: a lane's fragment address is base(pixel) + tapoff(t).  Strides and parity
+//     classes only change base(pixel).
+//   * Two workgroups share a CU (<= 80 KB of LDS and <= 256 registers each), so one workgroup's staging, barriers,
+//     prologue and epilogue run under the other's MFMAs.  Within a workgroup the global loads of the next weight
+//     tile (pre-split planes, [tap][co][ci] with ci contiguous) and, at a chunk's last tap, of the next input
+//     chunk are issued before the step's MFMAs and committed to LDS (split into planes there) after them.
+//   * Workgroup ids are remapped so that an XCD receives a contiguous range of tiles (neighbouring tiles share
+//     halo rows and all channel tiles of a pixel tile share the input through that XCD's L2).
+#include "common.h"
+#include <cstring>
+#include <cstdlib>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KC = 32;        // input channels per K-step = K of one 16x16x32 MFMA
+constexpr int BN = 64;        // output channels per workgroup
+constexpr int MAXTAPS = 25;
+constexpr int LDS_TOTAL = 160 * 1024;
+// two workgroups per CU (<= 80 KB LDS, <= 256 registers each); three smaller ones measured slower (MF = 2: 5.7 vs
+// 5.2 ms on the 64-channel layer: the weight-fragment reads per MFMA double)
+constexpr int wgs_per_cu(int) { return 2; }
+// A-staging passes of the next chunk prefetched into registers under the MFMAs
+constexpr int max_prefetch(int) { return 12; }
+
+struct IgemmParams {
+  const void* in;             // [N][Hi][Wi][Ci]
+  const unsigned short* wp;   // [NPL][ntw][Cop][Cip] bf16 planes, ci contiguous
+  void* out;                  // [N][Hout][Wout][Co]
+  const float* bias;          // [Co] or null
+  int N, Hi, Wi, Ci, Cip;
+  int Hout, Wout, Co, Cop;
+  int Hs, Ws, so, poy, pox, si;
+  int TI, TR, tiles_per_img, n_mtiles, n_ntiles;
+  int IR, WS, PL, IS, NS, aymin;
+  int ntaps, ntw, npass, region_px;
+  float inv_ws, inv_tr, inv_wi, inv_irwi;
+  int tap_off[MAXTAPS];       // slot offset of tap t relative to a pixel's base slot
+  int tap_w[MAXTAPS];         // index of tap t in the weight tensor
+  int ablate;                 // diagnostics (BLADES_IGEMM_ABLATE): 1 no staging loads, 2 no commit, 4 no MFMAs
+};
+
+// exact for 0 <= e < 2^20, 1 <= d < 2^12: (e + 0.5) / d is at least 0.5/d away from any integer
+__device__ __forceinline__ int fdiv(int e, float inv_d) { return __float2int_rz(((float)e + 0.5f) * inv_d); }
+
+template <int NPL>
+__device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NPL]) {
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    const bf16x4 b = __builtin_convertvector(r, bf16x4);
+    pl[q] = __builtin_bit_cast(u32x2, b);
+    if (q + 1 < NPL) r -= __builtin_convertvector(b, f32x4);
+  }
+}
+
+template <int NPL, int MF, bool SPLIT>
+__global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const IgemmParams p) {
+  static_assert(SPLIT || NPL == 1, "bf16 input has a single plane");
+  constexpr int MAXPF = max_prefetch(MF);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_xcd = gridDim.x >> 3;
+  const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (lid >= p.n_mtiles * p.n_ntiles) return;  // whole workgroup leaves: no barrier is skipped by a subset
+  const int nt = lid % p.n_ntiles, mt = lid / p.n_ntiles;
+  const int n0 = nt * BN;
+  int img0, sy0;
+  if (p.TI == 1) { img0 = mt / p.tiles_per_img; sy0 = (mt - img0 * p.tiles_per_img) * p.TR; }
+  else { img0 = mt * p.TI; sy0 = 0; }
+  const int iy_lo = sy0 * p.si + p.aymin;
+
+  const int a_plane = p.NS * 64, a_buf = NPL * a_plane;
+  constexpr int b_plane = BN * 64;
+  unsigned char* A_lds = smem;          // [NPL][NS slots][32 ch] bf16
+  unsigned char* B_lds = smem + a_buf;  // [NPL][64 co][32 ci] bf16
+  for (int i = tid * 16; i < a_buf; i += 256 * 16) *reinterpret_cast<u32x4*>(A_lds + i) = u32x4{0, 0, 0, 0};
+
+  // Both LDS images have 64-byte rows (32 channels of one slot / one output channel).  A fragment read
+  // (ds_read_b128: lane -> row li, 16-byte channel group kg) of 16 consecutive rows would put four lanes of
+  // every 16-lane service group on the same banks; XOR-ing bit 1 of the channel group with bit 2 of the row
+  // makes those reads conflict-free.  Stores apply the same involution.
+  auto swz = [](int row) { return (row & 4) << 3; };
+
+  // ---- this lane's output pixels: fragment pf, column li ---------------------------------------------------
+  const int li = lane & 15, kg = lane >> 4;
+  int a_slot[MF];
+  long out_pix[MF];
+#pragma unroll
+  for (int pf = 0; pf < MF; ++pf) {
+    const int m = (wave * MF + pf) * 16 + li;
+    const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
+    const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
+    const bool ok = il < p.TI && sy0 + ry < p.Hs && img0 + il < p.N;
+    a_slot[pf] = ok ? il * p.IS + ry * p.si * p.WS + sx * p.si + p.PL : p.PL;
+    out_pix[pf] = ok ? ((long)(img0 + il) * p.Hout + (sy0 + ry) * p.so + p.poy) * p.Wout + sx * p.so + p.pox : -1;
+  }
+
+  // ---- staging roles -----------------------------------------------------------------------------------------
+  // A: one pass = PIXPP region pixels x 32 channels; lane group (cg) covers CPL channels of a pixel (16 bytes)
+  constexpr int CPL = SPLIT ? 4 : 8, LPP = KC / CPL, PIXPP = 256 / LPP;
+  const int cg = tid % LPP, pp = tid / LPP;
+  struct ADesc { long goff; int slot; };
+  auto a_desc = [&](int pass) {
+    ADesc d;
+    const int e = pass * PIXPP + pp;
+    const int il = fdiv(e, p.inv_irwi), rem = e - il * p.IR * p.Wi;
+    const int r = fdiv(rem, p.inv_wi), ix = rem - r * p.Wi;
+    const int iy = iy_lo + r;
+    const bool ok = e < p.region_px && (unsigned)iy < (unsigned)p.Hi && img0 + il < p.N;
+    d.slot = il * p.IS + r * p.WS + ix + p.PL;
+    d.goff = ok ? (((long)(img0 + il) * p.Hi + iy) * p.Wi + ix) * p.Ci : -1;
+    return d;
+  };
+  const bool vec_in = (p.Ci % CPL) == 0;
+  auto a_load = [&](const ADesc& d, int c0) {
+    u32x4 v = {0, 0, 0, 0};
+    const int ch = c0 + cg * CPL;
+    if (d.goff >= 0 && ch < p.Ci) {
+      if constexpr (SPLIT) {
+        const float* src = reinterpret_cast<const float*>(p.in) + d.goff + ch;
+        if (vec_in) v = *reinterpret_cast<const u32x4*>(src);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ch + j < p.Ci ? __float_as_uint(src[j]) : 0u;
+        }
+      } else {
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(p.in) + d.goff + ch;
+        if (vec_in) v = *reinterpret_cast<const u32x4*>(src);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned e = ch + j < p.Ci ? src[j] : 0u;
+            v[j >> 1] |= e << ((j & 1) * 16);
+          }
+        }
+      }
+    }
+    return v;
+  };
+  auto a_store = [&](const ADesc& d, u32x4 v) {
+    if (d.goff < 0) return;  // outside the image / region: the slot keeps its zero fill
+    if constexpr (SPLIT) {
+      unsigned char* dst = A_lds + d.slot * 64 + (((cg >> 1) * 16) ^ swz(d.slot)) + (cg & 1) * 8;
+      u32x2 pl[NPL];
+      split4<NPL>(__builtin_bit_cast(f32x4, v), pl);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(dst + q * a_plane) = pl[q];
+    } else {
+      *reinterpret_cast<u32x4*>(A_lds + d.slot * 64 + ((cg * 16) ^ swz(d.slot))) = v;
+    }
+  };
+  // whole-chunk staging with every load of a batch in flight before the first conversion
+  auto a_stage_sync = [&](int pass_begin, int c0) {
+    for (int j0 = pass_begin; j0 < p.npass; j0 += 4) {
+      ADesc d[4];
+      u32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d[j].goff = -1; d[j].slot = 0;
+        if (j0 + j < p.npass) d[j] = a_desc(j0 + j);
+        v[j] = a_load(d[j], c0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a_store(d[j], v[j]);
+    }
+  };
+  // B: weight tile of one step = NPL x [64 co][32 ci]; thread -> (co row tid >> 2, 8-channel group tid & 3)
+  const int brow = tid >> 2, bkg = tid & 3;
+  const size_t w_plane = (size_t)p.ntw * p.Cop * p.Cip;
+  auto b_load = [&](int tw, int c0, int q) {
+    return *reinterpret_cast<const u32x4*>(p.wp + q * w_plane + ((size_t)tw * p.Cop + n0 + brow) * p.Cip + c0 + bkg * 8);
+  };
+  const int b_dst = brow * 64 + ((bkg * 16) ^ swz(brow));
+  auto b_store = [&](u32x4 v, int q) { *reinterpret_cast<u32x4*>(B_lds + q * b_plane + b_dst) = v; };
+
+  f32x4 acc[MF][4];
+#pragma unroll
+  for (int pf = 0; pf < MF; ++pf)
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) acc[pf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = p.Cip / KC, nsteps = nchunks * p.ntaps;
+  __syncthreads();  // zero fill complete
+  if (nsteps > 0) {
+    a_stage_sync(0, 0);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q);
+  }
+  __syncthreads();
+
+  const unsigned char* Bb = B_lds + li * 64 + ((kg * 16) ^ swz(li));
+  int c = 0, t = 0;
+  for (int ks = 0; ks < nsteps; ++ks) {
+    int tn = t + 1, cn = c;
+    if (tn == p.ntaps) { tn = 0; cn = c + 1; }
+    const bool next_b = ks + 1 < nsteps && !(p.ablate & 1);
+    const bool next_a = tn == 0 && cn < nchunks && !(p.ablate & 1);  // this step ends chunk c: restage A after it
+    // 1. global loads: next step's weight tile; at a chunk's last tap also the next chunk of the input tile.
+    //    They complete under this step's MFMAs (and under the MFMAs of the workgroup sharing the CU).
+    u32x4 breg[NPL];
+    if (next_b) {
+      const int tw = p.tap_w[tn];
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) breg[q] = b_load(tw, cn * KC, q);
+    }
+    u32x4 areg[MAXPF];
+    if (next_a) {
+#pragma unroll
+      for (int j = 0; j < MAXPF; ++j) {
+        areg[j] = u32x4{0, 0, 0, 0};
+        if (j < p.npass) areg[j] = a_load(a_desc(j), cn * KC);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 2. MFMAs of (chunk c, tap t)
+    if (!(p.ablate & 4)) {
+      const int toff = p.tap_off[t];
+      bf16x8 wf[NPL][4];
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) wf[q][cf] = *reinterpret_cast<const bf16x8*>(Bb + q * b_plane + cf * 1024);
+#pragma unroll
+      for (int pf = 0; pf < MF; ++pf) {
+        const int s = a_slot[pf] + toff;
+        const unsigned char* Ab = A_lds + s * 64 + ((kg * 16) ^ swz(s));
+        bf16x8 af[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) af[q] = *reinterpret_cast<const bf16x8*>(Ab + q * a_plane);
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          // (weight plane, activation plane) pairs, small terms first
+          if constexpr (NPL == 3) {
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[1], acc[pf][cf], 0, 0, 0);
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[2], acc[pf][cf], 0, 0, 0);
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][cf], af[0], acc[pf][cf], 0, 0, 0);
+          }
+          if constexpr (NPL >= 2) {
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[1], acc[pf][cf], 0, 0, 0);
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[0], acc[pf][cf], 0, 0, 0);
+          }
+          acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[0], acc[pf][cf], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // every wave has read this step's fragments
+    // 3. commit the staged data
+    if (next_b && !(p.ablate & 2)) {
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) b_store(breg[q], q);
+    }
+    if (next_a && !(p.ablate & 2)) {
+#pragma unroll
+      for (int j = 0; j < MAXPF; ++j)
+        if (j < p.npass) a_store(a_desc(j), areg[j]);
+      a_stage_sync(MAXPF, cn * KC);  // geometries with more than MAXPF passes: the rest without prefetch
+    }
+    __syncthreads();
+    t = tn; c = cn;
+  }
+
+  // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
+  const bool vec_out = (p.Co % 4) == 0;
+#pragma unroll
+  for (int pf = 0; pf < MF; ++pf) {
+    if (out_pix[pf] < 0) continue;
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) {
+      const int co = n0 + cf * 16 + kg * 4;
+      if (co >= p.Co) continue;
+      f32x4 v = acc[pf][cf];
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? p.bias[co + j] : 0.f;
+      }
+      if constexpr (SPLIT) {
+        float* dst = reinterpret_cast<float*>(p.out) + out_pix[pf] * p.Co + co;
+        if (vec_out) *reinterpret_cast<f32x4*>(dst) = v;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = v[j];
+        }
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(p.out) + out_pix[pf] * p.Co + co;
+        const u32x2 b = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+        if (vec_out) *reinterpret_cast<u32x2*>(dst) = b;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = (unsigned short)(b[j >> 1] >> ((j & 1) * 16));
+        }
+      }
+    }
+  }
+}
+
+// Weight planes.  w is the PyTorch tensor [Co][Ci][taps] (fp32, contiguous).  transpose = 0 (forward):
+// wp[q][t][co][ci]; transpose = 1 (data gradient: the produced channels are the layer's input channels):
+// wp[q][t][ci][co].  Rows / columns beyond the real channel counts are zero.
+__global__ __launch_bounds__(256) void conv_wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
+                                                         int Co, int Ci, int taps, int rows, int rows_pad, int k,
+                                                         int k_pad, int transpose, int npl) {
+  const size_t total = (size_t)taps * rows_pad * k_pad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int kk = (int)(i % k_pad);
+    const size_t rr = i / k_pad;
+    const int row = (int)(rr % rows_pad), t = (int)(rr / rows_pad);
+    float v = 0.f;
+    if (row < rows && kk < k) {
+      const int co = transpose ? kk : row, ci = transpose ? row : kk;
+      v = w[((size_t)co * Ci + ci) * taps + t];
+    }
+    for (int q = 0; q < npl; ++q) {
+      const __bf16 b = (__bf16)v;
+      wp[q * total + i] = __builtin_bit_cast(unsigned short, b);
+      v -= (float)b;
+    }
+  }
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// Tile choice + geometry for one launch.  Returns the number of pixel fragments per wave (4, 2, 1), 0 = no fit.
+int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
+  int aymin = 0, aymax = 0, axmin = 0, axmax = 0;
+  for (int t = 0; t < p.ntaps; ++t) {
+    if (t == 0 || ay[t] < aymin) aymin = ay[t];
+    if (t == 0 || ay[t] > aymax) aymax = ay[t];
+    if (t == 0 || ax[t] < axmin) axmin = ax[t];
+    if (t == 0 || ax[t] > axmax) axmax = ax[t];
+  }
+  p.aymin = aymin;
+  p.PL = axmin < 0 ? -axmin : 0;
+  int overflow = (p.Ws - 1) * p.si + axmax - (p.Wi - 1);
+  if (overflow < 0) overflow = 0;
+  const int hpad = p.PL > overflow ? p.PL : overflow;
+  p.WS = p.Wi + hpad;
+  int padT = aymin < 0 ? -aymin : 0;
+  int padB = (p.Hs - 1) * p.si + aymax - (p.Hi - 1);
+  if (padB < 0) padB = 0;
+  const int share = padT < padB ? padT : padB;
+  int best_mf = 0;
+  double best_cost = 0;
+  IgemmParams best = p;
+  const char* force = getenv("BLADES_IGEMM_MF");
+  for (int mf = 4; mf >= 1; mf >>= 1) {
+    const int BM = 64 * mf;
+    if (p.Ws > BM) continue;
+    if (force && atoi(force) != mf) continue;
+    // candidates: TI whole images per tile (largest first), then row bands of one image (TR rows, fewest first
+    // that fits the 160 KB of LDS: the staged receptive field grows with stride and kernel size)
+    const int ti_max = p.Hs * p.Ws * 2 <= BM ? BM / (p.Hs * p.Ws) : 1;
+    int tr_max = BM / p.Ws;
+    if (tr_max > p.Hs) tr_max = p.Hs;
+    for (int ti = ti_max, tr = tr_max; ti >= 1 && tr >= 1;) {
+      IgemmParams q = p;
+      if (ti > 1) {
+        q.TI = ti; q.TR = p.Hs; q.tiles_per_img = 1;
+        q.n_mtiles = (p.N + q.TI - 1) / q.TI;
+      } else {
+        q.TI = 1;
+        q.tiles_per_img = (p.Hs + tr - 1) / tr;
+        q.TR = (p.Hs + q.tiles_per_img - 1) / q.tiles_per_img;
+        q.n_mtiles = p.N * q.tiles_per_img;
+      }
+      q.IR = (q.TR - 1) * p.si + (aymax - aymin) + 1;
+      const int rows = q.TI > 1 ? (q.TI - 1) * (q.IR - share) + q.IR : q.IR;
+      q.IS = q.TI > 1 ? (q.IR - share) * p.WS : q.IR * p.WS;
+      q.NS = round_up(rows * p.WS + hpad + p.PL + 1, 4);
+      const long lds = (long)npl * q.NS * 64 + (long)npl * BN * 64;
+      q.region_px = q.TI * q.IR * p.Wi;
+      const bool fits = lds <= LDS_TOTAL / wgs_per_cu(mf) && q.region_px < (1 << 20) && p.Wi < 4096 && q.IR * p.Wi < 4096 * 64;
+      if (fits) {
+        const double cost = (double)q.n_mtiles * BM * (mf == 4 ? 1.0 : mf == 2 ? 1.12 : 1.35);
+        if (best_mf == 0 || cost < best_cost) { best_mf = mf; best_cost = cost; best = q; }
+        break;
+      }
+      if (ti > 1) ti >>= 1; else --tr;
+    }
+  }
+  if (best_mf) p = best;
+  return best_mf;
+}
+
+template <int NPL, int MF, bool SPLIT>
+int launch(const IgemmParams& p, hipStream_t st) {
+  const size_t lds = (size_t)NPL * p.NS * 64 + (size_t)NPL * BN * 64;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<NPL, MF, SPLIT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / wgs_per_cu(MF));
+    attr = true;
+  }
+  const int blocks = p.n_mtiles * p.n_ntiles;
+  const int grid = (blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL((conv_igemm_kernel<NPL, MF, SPLIT>), dim3(grid), dim3(256), lds, st, p);
+  return 0;
+}
+
+int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t st) {
+  const int mf = plan(p, npl, ay, ax);
+  if (mf == 0) return 3;
+  const int PIXPP = npl == 1 ? 64 : 32;
+  p.npass = (p.region_px + PIXPP - 1) / PIXPP;
+  p.inv_ws = 1.0f / p.Ws; p.inv_tr = 1.0f / p.TR; p.inv_wi = 1.0f / p.Wi; p.inv_irwi = 1.0f / (p.IR * p.Wi);
+  for (int t = 0; t < p.ntaps; ++t) p.tap_off[t] = (ay[t] - p.aymin) * p.WS + ax[t];
+  p.n_ntiles = p.Cop / BN;
+  { const char* e = getenv("BLADES_IGEMM_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+#define GO(NPL, SPLIT)                                           \
+  do {                                                           \
+    if (mf == 4) return launch<NPL, 4, SPLIT>(p, st);            \
+    if (mf == 2) return launch<NPL, 2, SPLIT>(p, st);            \
+    return launch<NPL, 1, SPLIT>(p, st);                         \
+  } while (0)
+  if (npl == 3) GO(3, true);
+  if (npl == 2) GO(2, true);
+  if (npl == 1) GO(1, false);
+#undef GO
+  return 4;
+}
+
+}  // namespace
+
+// bytes of weight-plane workspace a call needs
+BLADES_API long blades_conv_igemm_ws(int Co, int Ci, int kh, int kw, int mode, int npl) {
+  const int rows = mode == 0 ? Co : Ci, k = mode == 0 ? Ci : Co;
+  return (long)npl * kh * kw * round_up(rows, BN) * round_up(k, KC) * 2;
+}
+
+// mode 0: forward    in = x  [N,H,W,Ci]   -> out = y  [N,Ho,Wo,Co]   (bias optional)
+// mode 1: data grad  in = gy [N,Ho,Wo,Co] -> out = dx [N,H,W,Ci]
+// w: [Co][Ci][kh][kw] fp32 contiguous.  npl 3 / 2: fp32 tensors; npl 1: bf16 tensors.
+// returns 0 ok; nonzero = unsupported (caller falls back)
+BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
+                                 int W, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad, int mode,
+                                 int npl, hipStream_t st) {
+  if (npl < 1 || npl > 3 || kh * kw > MAXTAPS || stride < 1 || N <= 0) return 1;
+  if (Ho != (H + 2 * pad - kh) / stride + 1 || Wo != (W + 2 * pad - kw) / stride + 1) return 2;
+  const int taps = kh * kw;
+  const int rows = mode == 0 ? Co : Ci, k = mode == 0 ? Ci : Co;
+  const int rows_pad = round_up(rows, BN), k_pad = round_up(k, KC);
+  {
+    const size_t total = (size_t)taps * rows_pad * k_pad;
+    int gx = cdiv((long)total, 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(conv_wprep_kernel, dim3(gx), dim3(256), 0, st, w, (unsigned short*)ws, Co, Ci, taps, rows,
+                       rows_pad, k, k_pad, mode, npl);
+  }
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = in; p.wp = (const unsigned short*)ws; p.out = out; p.bias = mode == 0 ? bias : nullptr;
+  p.N = N; p.ntw = taps; p.Cop = rows_pad; p.Cip = k_pad;
+  int ay[MAXTAPS], ax[MAXTAPS];
+  if (mode == 0) {
+    p.Hi = H; p.Wi = W; p.Ci = Ci; p.Hout = Ho; p.Wout = Wo; p.Co = Co;
+    p.Hs = Ho; p.Ws = Wo; p.so = 1; p.poy = 0; p.pox = 0; p.si = stride;
+    p.ntaps = taps;
+    for (int r = 0; r < kh; ++r)
+      for (int s = 0; s < kw; ++s) { ay[r * kw + s] = r - pad; ax[r * kw + s] = s - pad; p.tap_w[r * kw + s] = r * kw + s; }
+    return dispatch(p, npl, ay, ax, st);
+  }
+  p.Hi = Ho; p.Wi = Wo; p.Ci = Co; p.Hout = H; p.Wout = W; p.Co = Ci;
+  p.so = stride; p.si = 1;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      if (ph >= H || pw >= W) continue;
+      IgemmParams q = p;
+      q.poy = ph; q.pox = pw;
+      q.Hs = (H - ph + stride - 1) / stride; q.Ws = (W - pw + stride - 1) / stride;
+      int n = 0;
+      for (int r = 0; r < kh; ++r) {
+        if ((ph + pad - r) % stride != 0) continue;
+        for (int s = 0; s < kw; ++s) {
+          if ((pw + pad - s) % stride != 0) continue;
+          ay[n] = (ph + pad - r) / stride; ax[n] = (pw + pad - s) / stride; q.tap_w[n] = r * kw + s;
+          ++n;
+        }
+      }
+      q.ntaps = n;
+      const int rc = dispatch(q, npl, ay, ax, st);
+      if (rc != 0) return rc;
+    }
+  return 0;
+}
