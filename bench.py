@@ -1,7 +1,13 @@
 """Headline benchmark: FL rounds/sec, CIFAR-10-shaped data, ResNet-18, ALIE + robust aggregation.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 it starts N ranks itself,
+                                                              one process per GPU, before touching a GPU)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Compute dtype: fp32 by default, like the reference (fllib/tasks/task.py:170-186 has no autocast): activations,
+gradients and updates are fp32 tensors; the convolution kernels evaluate their products on the bf16 matrix cores
+after splitting every fp32 operand *exactly* into three bf16 planes (6 MFMA products, fp32 accumulation: error
+below one fp32 rounding per product).  ``--amp bf16x3`` (two planes) and ``--amp bf16`` are labelled as such.
 
 One *step* is one complete FL round of the named config (BASELINE.json: "CIFAR-10 ResNet-18,
 1000 simulated clients/round sharded across the GPUs", 20 % ALIE attackers, coordinate-wise
@@ -39,16 +45,24 @@ def main():
     ap.add_argument("--aggregator", default="Median")
     ap.add_argument("--adversary", default="ALIEAdversary")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=400,
+    ap.add_argument("--chunk", type=int, default=0,
                     help="clients vectorised per kernel chunk (400 x 64 samples: 102 GB peak HBM on ResNet-18, +3 %% "
                          "over 200; multi-GPU runs use at most half a rank's clients so the exchange overlaps)")
-    ap.add_argument("--amp", default="bf16")
+    ap.add_argument("--amp", default="fp32", help="fp32 (reference precision, default) | bf16x3 | bf16")
     ap.add_argument("--samples-per-client", type=int, default=128)
     ap.add_argument("--local-steps", type=int, default=1, help="client SGD steps per round (1 = FedSGD headline)")
     ap.add_argument("--cpu", action="store_true", help="debug: run on CPU/gloo")
     ap.add_argument("--torch-profile", default=None,
                     help="after the timed rounds, run one more under torch.profiler and write the op table here")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: become the launcher of N ranks (reference analogue:
+        # WorkerGroup bring-up, fllib/core/execution/worker_group.py:41-62).  This process never initialises a
+        # GPU; rank 0 prints the JSON line, the exit status is the first failing rank's.
+        from blades_amd.parallel.launcher import launch
+
+        sys.exit(launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -64,7 +78,7 @@ def main():
     K = args.clients
     f = int(round(args.malicious_frac * K))
     agg = {"type": args.aggregator}
-    chunk = args.chunk
+    chunk = args.chunk or (400 if args.amp == "bf16" else 200)  # fp32 activations take twice the bytes
     if world > 1:
         # at least two chunks per rank, so the all-to-all of the first overlaps the training of the second
         chunk = max(1, min(chunk, -(-(K - f) // (2 * world))))
@@ -81,7 +95,7 @@ def main():
            .adversary(num_malicious_clients=f,
                       adversary_config={"type": f"blades.adversaries.{args.adversary}"})
            .evaluation(evaluation_interval=0)
-           .engine(clients_per_chunk=chunk, amp_dtype=None if args.amp == "fp32" else args.amp))
+           .engine(clients_per_chunk=chunk, amp_dtype=args.amp))
     algo = cfg.build()
 
     def sync():
@@ -146,7 +160,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16" if args.amp == "bf16" else args.amp,
+            "dtype": algo.engine.compute_dtype,
+            "dtype_note": {"fp32": "fp32 tensors; conv products as exact 3xbf16 operand split (6 MFMA), fp32 accumulate",
+                           "bf16x3": "fp32 tensors; conv products as 2xbf16 split (3 MFMA), fp32 accumulate",
+                           "bf16": "bf16 activations, fp32 updates"}.get(algo.engine.compute_dtype, ""),
             "data": f"synthetic ({args.dataset} shape, random-init weights)",
             "config": {
                 "model": args.model, "dataset": args.dataset, "num_clients": K, "num_malicious": f,

@@ -39,6 +39,9 @@ class GradSink:
         self.B = 0
         self.offsets: Dict[int, tuple] = {}  # id(param) -> (offset, numel)
         self._written = set()
+        # operand planes of the hand-written convolution kernels (ops/csrc/conv_igemm.hip, conv_wgrad.hip):
+        # 3 = fp32 activations, exact 3 x bf16 split (fp32 grade); 2 = fp32 activations, "bf16x3"; 1 = bf16
+        self.npl = 3
 
     def begin(self, block, scale, Kc, B):
         self.block, self.scale, self.Kc, self.B = block, scale, Kc, B
@@ -61,6 +64,19 @@ class GradSink:
 
 # ---------------------------------------------------------------------------
 _DGRAD_AS_FWD = _os.environ.get("BLADES_DGRAD_AS_FWD", "1") != "0"
+# "hip" (default): forward and data-gradient convolutions run ops/csrc/conv_igemm.hip; "miopen": the library's
+# kernels (A/B comparisons only — the fp32 library path has no matrix-core kernel on gfx950)
+_CONV_IMPL = _os.environ.get("BLADES_CONV_IMPL", "hip").lower()
+
+
+def _own_conv(x, mod) -> bool:
+    """Does ops/csrc/conv_igemm.hip run this layer?  (GPU, channels-last 4-D input of the kernels' dtype.)"""
+    if not (x.is_cuda and x.dim() == 4 and _CONV_IMPL == "hip"):
+        return False
+    npl = mod.sink.npl
+    if x.dtype != (torch.bfloat16 if npl == 1 else torch.float32):
+        return False
+    return _hipmod().conv_igemm_supported(x, mod.weight, mod.stride, mod.padding, mod.dilation, npl)
 
 
 def dgrad_same_conv(gy: torch.Tensor, w: torch.Tensor, padding) -> torch.Tensor:
@@ -87,6 +103,12 @@ class _PCConvFn(torch.autograd.Function):
                 x = x.contiguous(memory_format=torch.channels_last)
             w = w.contiguous(memory_format=torch.channels_last)
         ctx.mod = mod
+        ctx.own = _own_conv(x, mod)
+        if ctx.own:
+            # hand-written implicit-GEMM kernel; reads the fp32 master weights itself (split into bf16 planes)
+            ctx.save_for_backward(x, weight.detach())
+            return _hipmod().conv_forward(x, weight.detach(), mod.bias, int(mod.stride[0]), int(mod.padding[0]),
+                                          mod.sink.npl)
         ctx.save_for_backward(x, w)
         return F.conv2d(x, w, b, mod.stride, mod.padding, mod.dilation, 1)
 
@@ -98,7 +120,10 @@ class _PCConvFn(torch.autograd.Function):
         Kc, B = sink.Kc, sink.B
         gy = gy.contiguous(memory_format=torch.channels_last) if gy.dim() == 4 else gy
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.own:
+            dx = _hipmod().conv_dgrad(gy, w, (int(x.shape[2]), int(x.shape[3])), int(mod.stride[0]),
+                                      int(mod.padding[0]), sink.npl)
+        elif ctx.needs_input_grad[0]:
             ks = w.shape[2:]
             same = (gy.is_cuda and _DGRAD_AS_FWD and tuple(mod.stride) == (1, 1) and tuple(mod.dilation) == (1, 1)
                     and ks[0] % 2 == 1 and ks[1] % 2 == 1
@@ -145,7 +170,17 @@ class PCConv2d(nn.Module):
         off, _ = sink.offsets[id(self.weight)]
         acc = id(self.weight) in sink._written
         ok = h.conv_wgrad_(x, gy, Kc, sink.block, off, sink.scale, acc, int(ks[0]), int(self.stride[0]),
-                           int(self.padding[0]))
+                           int(self.padding[0]), sink.npl)
+        if not ok and int(self.stride[0]) == 2 and int(ks[0]) == 3 and int(self.padding[0]) == 1 \
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            # The split planes of a strided 3x3 layer's input window do not fit in LDS.  Its weight gradient is
+            # the stride-1 weight gradient against gy spread onto the input grid (zeros in between): same
+            # kernel, fast path, at 4x the MFMA work of these three (of twenty) layers.
+            N, Co, Ho, Wo = gy.shape
+            up = torch.empty((N, Co, 2 * Ho, 2 * Wo), dtype=gy.dtype, device=gy.device,
+                             memory_format=torch.channels_last).zero_()
+            up[:, :, ::2, ::2] = gy
+            ok = h.conv_wgrad_(x, up, Kc, sink.block, off, sink.scale, acc, 3, 1, 1, sink.npl)
         if ok:
             sink._written.add(id(self.weight))
         return ok
@@ -516,7 +551,7 @@ class FusedFedSGD:
     """Runs one shared-weight forward/backward for a chunk of clients and leaves
     ``scale_c * dL_c/dtheta`` in the chunk's rows of the update matrix."""
 
-    def __init__(self, task, names, offsets, numels, amp_dtype, device):
+    def __init__(self, task, names, offsets, numels, amp_dtype, device, conv_planes: int = 3):
         self.task = task
         self.sink = GradSink()
         self.template = build_template(task.model, self.sink)
@@ -524,6 +559,7 @@ class FusedFedSGD:
             self.sink.offsets[id(p)] = (int(o), int(m))
         self.amp_dtype = amp_dtype
         self.device = device
+        self.sink.npl = 1 if amp_dtype == torch.bfloat16 else (2 if conv_planes == 2 else 3)
 
     def run(self, X: torch.Tensor, Y: torch.Tensor, block: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
         """X [Kc, B, ...], Y [Kc, B]; ``block`` = the chunk's rows of U (row stride

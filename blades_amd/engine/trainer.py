@@ -51,8 +51,10 @@ def _autocast(device: torch.device, dtype: Optional[torch.dtype]):
     return torch.autocast(device_type=device.type, dtype=dtype)
 
 
-_DTYPES = {None: None, "fp32": None, "float32": None, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
-           "fp16": torch.float16, "float16": torch.float16}
+# "fp32": fp32 activations; the hand-written convolution kernels split them exactly into 3 bf16 planes (6 MFMA
+# products, fp32 grade).  "bf16x3": fp32 activations, 2 planes / 3 products (~2^-17).  "bf16": bf16 activations.
+_DTYPES = {None: None, "fp32": None, "float32": None, "bf16x3": None, "bf16": torch.bfloat16,
+           "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16}
 
 
 class ClientEngine:
@@ -82,8 +84,11 @@ class ClientEngine:
         self.num_classes = num_classes
         self.mode = execution_mode
         if amp_dtype == "auto":
-            amp_dtype = "bf16" if self.device.type == "cuda" else None
+            amp_dtype = "fp32"  # the reference trains in fp32 (fllib/tasks/task.py:170-186); bf16 is opt-in
+        self.conv_planes = 2 if amp_dtype == "bf16x3" else 3
         self.amp_dtype = _DTYPES[amp_dtype] if not isinstance(amp_dtype, torch.dtype) else amp_dtype
+        self.compute_dtype = ("bf16x3" if self.conv_planes == 2 else
+                              {None: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}[self.amp_dtype])
         self.timers: Dict[str, float] = {}
         self.round = 0
         if self.device.type == "cuda":
@@ -155,7 +160,8 @@ class ClientEngine:
 
         self.fused = None
         if self.mode in ("auto", "batched", "fused") and fused.supports(task.model):
-            self.fused = fused.FusedFedSGD(task, self.names, self.offsets, self.numels, self.amp_dtype, self.device)
+            self.fused = fused.FusedFedSGD(task, self.names, self.offsets, self.numels, self.amp_dtype, self.device,
+                                           conv_planes=self.conv_planes)
         # several local steps: per-client weights -> grouped wide-network executor, if the model passes its
         # layout self-check (otherwise the torch.vmap path)
         self.grouped = None

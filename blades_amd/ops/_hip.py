@@ -55,11 +55,11 @@ _gram = _sig("blades_gram", [_P, c_long, c_int, c_long, _P, _P, _P])
 _augment = _sig("blades_augment_batch", [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P], c_int)
 
 
-_pcbn_nchunk = _sig("blades_pcbn_nchunk", [c_int, c_int], c_int)
+_pcbn_nchunk = _sig("blades_pcbn_nchunk", [c_int, c_int, c_int], c_int)
 _pcbn_fwd = _sig("blades_pcbn_forward", [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
-                                         _P], c_int)
+                                         c_int, _P], c_int)
 _pcbn_bwd = _sig("blades_pcbn_backward", [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_long, c_long, c_long,
-                                          c_int, _P, _P, _P, _P, _P, _P, _P], c_int)
+                                          c_int, _P, _P, _P, _P, _P, _P, c_int, _P], c_int)
 
 
 def _stream():
@@ -328,40 +328,46 @@ def augment_batch(x, params, size, mean, std, validate: bool = True):
 
 
 # ---------------------------------------------------------------------------
-def _chk_nhwc_bf16(t: torch.Tensor, name: str):
-    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4
+_ACT_DTYPES = (torch.bfloat16, torch.float32)
+
+
+def _chk_nhwc_bf16(t: torch.Tensor, name: str, dtype=torch.bfloat16):
+    if not (t.is_cuda and t.dtype == dtype and t.dim() == 4
             and t.is_contiguous(memory_format=torch.channels_last)):
-        raise ValueError(f"{name}: expected a CUDA bf16 channels-last 4-D tensor, got {t.dtype} {tuple(t.shape)} "
+        raise ValueError(f"{name}: expected a CUDA {dtype} channels-last 4-D tensor, got {t.dtype} {tuple(t.shape)} "
                          f"strides {t.stride()}")
 
 
 def pcbn_supported(x: torch.Tensor) -> bool:
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0 and x.shape[1] <= 2048
+    return (x.is_cuda and x.dtype in _ACT_DTYPES and x.dim() == 4 and x.shape[1] % 8 == 0 and x.shape[1] <= 2048
             and 256 % (x.shape[1] // 8) == 0
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
 def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask: bool = False):
-    _chk_nhwc_bf16(x, "x")
+    if x.dtype not in _ACT_DTYPES:
+        raise ValueError(f"pcbn_forward: unsupported dtype {x.dtype}")
+    _chk_nhwc_bf16(x, "x", x.dtype)
     N, C, H, W = x.shape
     if N % Kc != 0:
         raise ValueError("batch is not a multiple of the number of clients")
     P = (N // Kc) * H * W
     if res is not None:
-        _chk_nhwc_bf16(res, "res")
+        _chk_nhwc_bf16(res, "res", x.dtype)
         if res.shape != x.shape:
             raise ValueError("residual shape mismatch")
     dev = x.device
     gamma = _vec(gamma, C, dev, name="gamma")
     beta = _vec(beta, C, dev, name="beta")
-    nch = _pcbn_nchunk(P, C)
+    nch = _pcbn_nchunk(P, C, x.element_size())
     partial = torch.empty(Kc * nch * C * 2, device=dev)
     stats = torch.empty(4, Kc, C, device=dev)
     y = torch.empty_like(x)
     # ReLU gate for the backward pass: 1 bit per element (8 channels of a pixel = 1 byte) instead of y itself
     mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (relu and want_mask) else None
     rc = _pcbn_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), Kc, P, C, eps, int(relu), _ptr(partial),
-                   _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(y), _ptr(mask), _stream())
+                   _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(y), _ptr(mask), x.element_size(),
+                   _stream())
     if rc != 0:
         raise ValueError("pcbn_forward: unsupported shape")
     if want_mask:
@@ -372,8 +378,10 @@ def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask
 def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block, off_gamma: int, off_beta: int,
                   accumulate: bool, want_gres: bool):
     """``relu_mask``: the uint8 bitmask returned by ``pcbn_forward(..., want_mask=True)`` (``None`` = no ReLU)."""
-    _chk_nhwc_bf16(x, "x")
-    _chk_nhwc_bf16(gy, "gy")
+    if x.dtype not in _ACT_DTYPES:
+        raise ValueError(f"pcbn_backward: unsupported dtype {x.dtype}")
+    _chk_nhwc_bf16(x, "x", x.dtype)
+    _chk_nhwc_bf16(gy, "gy", x.dtype)
     if gy.shape != x.shape:
         raise ValueError("gy shape mismatch")
     if relu_mask is not None:
@@ -392,14 +400,14 @@ def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block,
         coef = _vec(coef, Kc, dev, name="coef")
     if mean.numel() != Kc * C or invstd.numel() != Kc * C:
         raise ValueError("pcbn_backward: stats shape mismatch")
-    nch = _pcbn_nchunk(P, C)
+    nch = _pcbn_nchunk(P, C, x.element_size())
     partial = torch.empty(Kc * nch * C * 2, device=dev)
     k = torch.empty(3, Kc, C, device=dev)
     dx = torch.empty_like(x)
     gres = torch.empty_like(x) if want_gres else None
     rc = _pcbn_bwd(_ptr(x), _ptr(gy), _ptr(relu_mask), _ptr(gamma), _ptr(mean), _ptr(invstd), Kc, P, C, _ptr(coef),
                    _ptr(U_block), ld, off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(k[0]), _ptr(k[1]),
-                   _ptr(k[2]), _ptr(dx), _ptr(gres), _stream())
+                   _ptr(k[2]), _ptr(dx), _ptr(gres), x.element_size(), _stream())
     if rc != 0:
         raise ValueError("pcbn_backward: unsupported shape")
     return dx, gres
@@ -408,7 +416,7 @@ def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block,
 # ---------------------------------------------------------------------------
 # per-client conv weight gradient
 _conv_wgrad = _sig("blades_conv_wgrad", [_P, _P, _P, c_long, c_long, _P, c_int] + [c_int] * 11 + [_P] + [c_int] * 5
-                   + [_P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, _P], c_int)
+                   + [_P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, c_int, _P], c_int)
 _wgrad_plans = {}
 
 
@@ -509,7 +517,7 @@ def _scratch(n: int, device) -> torch.Tensor:
 
 
 def conv_wgrad_supported(x, gy, ks, stride, pad, dilation) -> bool:
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and gy.dtype == torch.bfloat16 and x.dim() == 4):
+    if not (x.is_cuda and x.dtype in _ACT_DTYPES and gy.dtype == x.dtype and x.dim() == 4):
         return False
     Cin, Cout = x.shape[1], gy.shape[1]
     if (Cin % 16 and Cin > 16) or Cout % 16 or ks[0] != ks[1] or ks[0] not in (1, 3) or stride[0] != stride[1] \
@@ -520,10 +528,17 @@ def conv_wgrad_supported(x, gy, ks, stride, pad, dilation) -> bool:
     return True
 
 
-def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: int, stride: int, pad: int):
-    """Writes coef[c] * dW_c into U_block[c, off : off + Cout*Cin*ks*ks] for every client c."""
-    _chk_nhwc_bf16(x, "x")
-    _chk_nhwc_bf16(gy, "gy")
+def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: int, stride: int, pad: int,
+                npl: int = 0):
+    """Writes coef[c] * dW_c into U_block[c, off : off + Cout*Cin*ks*ks] for every client c.
+    bf16 activations run as they are; fp32 activations are split in-kernel into ``npl`` bf16 planes
+    (3 = fp32 grade, 2 = "bf16x3")."""
+    if x.dtype == torch.bfloat16:
+        npl = 1
+    elif npl not in (2, 3):
+        npl = 3
+    _chk_nhwc_bf16(x, "x", x.dtype)
+    _chk_nhwc_bf16(gy, "gy", x.dtype)
     N, Cin, H, W = x.shape
     N2, Cout, Ho, Wo = gy.shape
     if N != N2 or N % Kc:
@@ -575,7 +590,8 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
         scratch = _scratch(split * Kc * numel, x.device)
     rc = _conv_wgrad(_ptr(x), _ptr(gy), _ptr(U_block), ld, off, _ptr(coef), int(accumulate), Kc, B, H, W, Cin, Ho,
                      Wo, Cout, ks, stride, pad, _ptr(plan["table"]), plan["nsteps"], plan["nlines"], plan["wslots"],
-                     tmt, split, _ptr(scratch), rmul, cmul, plan["passes"], plan["rows_r"], plan["rows_off"], x_client_stride, cin_store, _stream())
+                     tmt, split, _ptr(scratch), rmul, cmul, plan["passes"], plan["rows_r"], plan["rows_off"], x_client_stride,
+                     cin_store, npl, _stream())
     if rc == 3:  # staging does not fit in LDS
         return False
     if rc != 0:

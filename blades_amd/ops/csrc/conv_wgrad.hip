@@ -43,6 +43,7 @@
 // stride-2 260-340, 1x1 190-220; per-layer ablations and PMC counters are in profiles/.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -58,8 +59,8 @@ constexpr int TBL = 48;         // ints per step (192 B, 64 B-aligned rows): 8 q
                                 // then row_lo, row_hi, window_lo at [32], [33], [34]
 
 struct WgradParams {
-  const unsigned short* x;
-  const unsigned short* gy;
+  const void* x;   // bf16 (NPL == 1) or fp32 (NPL == 2, 3: split into bf16 planes on the way into LDS)
+  const void* gy;
   float* U;
   long ld, off;
   const float* coef;
@@ -113,9 +114,28 @@ __device__ __forceinline__ void wait_vmcnt() {
 // FAST: output geometry is all powers of two (every ResNet layer), so a quad's (image, row, column) and the gy
 // pixel range of a step follow from the step index by shifts — no descriptor loads at all in the K loop; only
 // the range of new input rows still comes from the table (one 8-byte scalar load, fetched a step early).
-template <int TMT, int KS, int MAXP, int NPF, bool FAST>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
+// NPL: operand planes.  1 = bf16 activations as they are.  2 / 3 = fp32 activations, split exactly into bf16 planes
+// (x = h + m (+ l)) when a staged tile is committed to LDS; every plane pair that matters is multiplied
+// (NPL = 3: hh + hm + mh + hl + lh + mm, fp32 grade; NPL = 2: hh + hm + mh) into the same fp32 accumulators.
+template <int NPL>
+__device__ __forceinline__ void split8(const u32x4 lo, const u32x4 hi, u32x4 (&pl)[NPL]) {
+  typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+  f32x4 r0 = __builtin_bit_cast(f32x4, lo), r1 = __builtin_bit_cast(f32x4, hi);
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    const bf16x4v b0 = __builtin_convertvector(r0, bf16x4v), b1 = __builtin_convertvector(r1, bf16x4v);
+    const u32x2v u0 = __builtin_bit_cast(u32x2v, b0), u1 = __builtin_bit_cast(u32x2v, b1);
+    pl[q] = u32x4{u0[0], u0[1], u1[0], u1[1]};
+    if (q + 1 < NPL) { r0 -= __builtin_convertvector(b0, f32x4); r1 -= __builtin_convertvector(b1, f32x4); }
+  }
+}
+
+template <int TMT, int KS, int MAXP, int NPF, bool FAST, int NPL>
+__global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int TAPS = KS * KS;
+  using elem_t = std::conditional_t<NPL == 1, unsigned short, float>;
+  constexpr int LPI = NPL == 1 ? 1 : 2;  // 16-byte loads per staged item (8 channels of one pixel)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, XCD-aware: hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so id -> id'
@@ -130,21 +150,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   const int c = rest % p.Kc, zsplit = rest / p.Kc;
   const int co0 = (tile / n_ci_tiles) * (TMT * 16);
   const int ci0 = (tile % n_ci_tiles) * 64;
-  unsigned char* gy_lds = smem;                    // [2][TMT][32 px][16 co] bf16
-  unsigned char* x_lds = smem + 2 * TMT * 1024;    // [4 ci-blocks][nlines][wslots][16 ci] bf16
+  constexpr int GYB = TMT * 1024;                        // one gy tile of one plane: [TMT][32 px][16 co] bf16
+  unsigned char* gy_lds = smem;                          // [2][NPL][TMT][32 px][16 co] bf16
+  unsigned char* x_lds = smem + 2 * NPL * GYB;           // [NPL][4 ci-blocks][nlines][wslots][16 ci] bf16
   const int plane_bytes = (p.nlines + 1) * p.wslots * 32;  // ring of nlines + one all-zero line (index nlines)
+  const int xpl_bytes = 4 * plane_bytes;                 // one precision plane of the x image
   const int line_mask = p.nlines - 1;
 
-  for (int i = tid * 16; i < 4 * plane_bytes; i += 256 * 16) *reinterpret_cast<u32x4*>(x_lds + i) = u32x4{0, 0, 0, 0};
+  for (int i = tid * 16; i < NPL * xpl_bytes; i += 256 * 16) *reinterpret_cast<u32x4*>(x_lds + i) = u32x4{0, 0, 0, 0};
 
-  const unsigned short* xc = p.x + (size_t)c * p.x_client_stride;
-  const unsigned short* gc = p.gy + (size_t)c * p.B * p.Ho * p.Wo * p.Cout;
+  const elem_t* xc = reinterpret_cast<const elem_t*>(p.x) + (size_t)c * p.x_client_stride;
+  const elem_t* gc = reinterpret_cast<const elem_t*>(p.gy) + (size_t)c * p.B * p.Ho * p.Wo * p.Cout;
 
   // ---- staging roles: 8 lanes x 16 B cover one pixel's 64-channel tile --------------------
   const int chunk = tid & 7, pix = tid >> 3;
   const bool gy_lane = chunk < TMT * 2 && (co0 + chunk * 8) < p.Cout;
   const bool x_lane = (ci0 + chunk * 8) < p.Cin;
-  struct Stg { u32x4 gy; u32x4 x[MAXP]; };
+  struct Item { u32x4 v[LPI]; };
+  struct Stg { Item gy; Item x[MAXP]; };
+  auto fetch = [&](const elem_t* src) {
+    Item it;
+#pragma unroll
+    for (int l = 0; l < LPI; ++l) it.v[l] = gload16_untracked(reinterpret_cast<const unsigned char*>(src) + 16 * l);
+    return it;
+  };
+  // one staged item -> its 16 bytes in every precision plane (plane q at dst + q * plane_stride)
+  auto put = [&](unsigned char* dst, int plane_stride, const Item& it) {
+    if constexpr (NPL == 1) {
+      *reinterpret_cast<u32x4*>(dst) = it.v[0];
+    } else {
+      u32x4 pl[NPL];
+      split8<NPL>(it.v[0], it.v[LPI - 1], pl);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(dst + q * plane_stride) = pl[q];
+    }
+  };
   Stg stg[NPF];
   // step table through the scalar cache: every index below is wave-uniform, so these loads never enter the
   // vector-memory queue and cannot force the in-flight staging loads to drain
@@ -176,10 +216,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     f.row_hi = T[33];
     return f;
   };
-  const unsigned short* zeros16 = reinterpret_cast<const unsigned short*>(p.table + (size_t)p.nsteps * TBL);
+  const elem_t* zeros16 = reinterpret_cast<const elem_t*>(p.table + (size_t)p.nsteps * TBL);  // >= 32 zero bytes
   int rlo[NPF], rhi[NPF];  // new-row range of the step held by each staging slot (needed again at commit)
   auto issue = [&](const StepInfo& f, Stg& rg) {
-    const unsigned short* ga = zeros16;
+    const elem_t* ga = zeros16;
     if constexpr (FAST) {
       const int gpix = f.step * 32 + pix;  // quads tile the flattened pixel list: a step is 32 consecutive pixels
       if (gy_lane && gpix < p.nquads * 4) ga = gc + (size_t)gpix * p.Cout + co0 + chunk * 8;
@@ -190,18 +230,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
       const int q = pix & 3;
       if (gy_lane && gbase >= 0 && ow0 + q < p.Wo) ga = gc + (size_t)(gbase + q) * p.Cout + co0 + chunk * 8;
     }
-    rg.gy = gload16_untracked(ga);
+    rg.gy = fetch(ga);
     const int npix = (f.row_hi - f.row_lo + 1) * p.W;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       const int e = i * 32 + pix;
-      const unsigned short* xa = zeros16;
+      const elem_t* xa = zeros16;
       if (x_lane && e < npix) {
         const int er = p.w_shift >= 0 ? (e >> p.w_shift) : e / p.W;
         const size_t pixel = (size_t)(f.row_lo + er) * p.rmul + (size_t)(e - er * p.W) * p.cmul;
         xa = xc + pixel * p.Cin + ci0 + chunk * 8;
       }
-      rg.x[i] = gload16_untracked(xa);
+      rg.x[i] = fetch(xa);
     }
     // The table-driven variants are register-tight enough for the compiler to spill; a spill of a staging
     // register before its load has landed would save garbage, so they wait here (they are the slow general
@@ -210,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   };
   auto commit = [&](int s, const Stg& rg, int row_lo, int row_hi) {
     if (chunk < TMT * 2)
-      *reinterpret_cast<u32x4*>(gy_lds + (s & 1) * TMT * 1024 + (chunk >> 1) * 1024 + pix * 32 + (chunk & 1) * 16) = rg.gy;
+      put(gy_lds + (s & 1) * NPL * GYB + (chunk >> 1) * 1024 + pix * 32 + (chunk & 1) * 16, GYB, rg.gy);
     const int npix = (row_hi - row_lo + 1) * p.W;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
@@ -219,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         const int er = p.w_shift >= 0 ? (e >> p.w_shift) : e / p.W;
         const int row = row_lo + er, iw = e - er * p.W + p.pad;
         const int slot = p.stride == 1 ? iw : (iw & 1) * p.half + (iw >> 1);
-        *reinterpret_cast<u32x4*>(x_lds + (chunk >> 1) * plane_bytes + ((row & line_mask) * p.wslots + slot) * 32 +
-                                  (chunk & 1) * 16) = rg.x[i];
+        put(x_lds + (chunk >> 1) * plane_bytes + ((row & line_mask) * p.wslots + slot) * 32 + (chunk & 1) * 16,
+            xpl_bytes, rg.x[i]);
       }
     }
   };
@@ -298,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     if (s + NPF + 1 < s_end) nxt = fetch_info(s + NPF + 1);  // scalar loads; consumed next iteration
     if (s + 1 < s_end) load_desc(s + 1);
     if (wave_active && !(p.ablate & 2)) {
-      const unsigned char* gy_buf = gy_lds + (s & 1) * TMT * 1024 + lq * 32 + lp * 8;
+      const unsigned char* gy_buf = gy_lds + (s & 1) * NPL * GYB + lq * 32 + lp * 8;
       // Row base pointers of the two quads this lane reads (t = 0, 1).  Input rows outside the image (and
       // quads past the end of the pixel list) point at the all-zero line, so fragments need no masking.
       const unsigned char* bp[KS][2];
@@ -312,42 +352,65 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         }
       // B fragments are fetched one kernel row ahead of the MFMAs that use them; the A fragments and row 0
       // go first.  sched_barriers keep the compiler from sinking the reads back down to their uses.
-      i32x2 hb[2][KS * 2];
+      i32x2 hb[2][NPL][KS * 2];
 #pragma unroll
-      for (int sx = 0; sx < KS; ++sx)
+      for (int q = 0; q < NPL; ++q)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) hb[0][sx * 2 + t] = tr_read(bp[0][t] + tapoff[sx]);
-      i32x4 a[TMT];
+        for (int sx = 0; sx < KS; ++sx)
 #pragma unroll
-      for (int m = 0; m < TMT; ++m) {
-        const i32x2 lo = tr_read(gy_buf + m * 1024 + (0 * 16 + g * 4) * 32);
-        const i32x2 hi = tr_read(gy_buf + m * 1024 + (1 * 16 + g * 4) * 32);
-        a[m] = i32x4{lo[0], lo[1], hi[0], hi[1]};
-      }
+          for (int t = 0; t < 2; ++t) hb[0][q][sx * 2 + t] = tr_read(bp[0][t] + q * xpl_bytes + tapoff[sx]);
+      i32x4 a[NPL][TMT];
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int m = 0; m < TMT; ++m) {
+          const i32x2 lo = tr_read(gy_buf + q * GYB + m * 1024 + (0 * 16 + g * 4) * 32);
+          const i32x2 hi = tr_read(gy_buf + q * GYB + m * 1024 + (1 * 16 + g * 4) * 32);
+          a[q][m] = i32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
 #pragma unroll
       for (int r = 0; r < KS; ++r) {
         if (r + 1 < KS) {
 #pragma unroll
-          for (int sx = 0; sx < KS; ++sx)
+          for (int q = 0; q < NPL; ++q)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) hb[(r + 1) & 1][sx * 2 + t] = tr_read(bp[r + 1][t] + tapoff[sx]);
+            for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+                hb[(r + 1) & 1][q][sx * 2 + t] = tr_read(bp[r + 1][t] + q * xpl_bytes + tapoff[sx]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sx = 0; sx < KS; ++sx) {
-          const i32x2 h0 = hb[r & 1][sx * 2 + 0], h1 = hb[r & 1][sx * 2 + 1];
-          const i32x4 b = {h0[0], h0[1], h1[0], h1[1]};
+          bf16x8 b[NPL];
 #pragma unroll
-          for (int m = 0; m < TMT; ++m)
-            acc[m][r * KS + sx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, a[m]), __builtin_bit_cast(bf16x8, b), acc[m][r * KS + sx], 0, 0, 0);
+          for (int q = 0; q < NPL; ++q) {
+            const i32x2 h0 = hb[r & 1][q][sx * 2 + 0], h1 = hb[r & 1][q][sx * 2 + 1];
+            b[q] = __builtin_bit_cast(bf16x8, i32x4{h0[0], h0[1], h1[0], h1[1]});
+          }
+#pragma unroll
+          for (int m = 0; m < TMT; ++m) {
+            f32x4 d = acc[m][r * KS + sx];
+            // (gy plane, x plane) pairs, small terms first
+            if constexpr (NPL == 3) {
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1][m]), b[1], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]), b[2], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[2][m]), b[0], d, 0, 0, 0);
+            }
+            if constexpr (NPL >= 2) {
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]), b[1], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1][m]), b[0], d, 0, 0, 0);
+            }
+            acc[m][r * KS + sx] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]), b[0], d, 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (s + 1 < s_end && !ablate_stage) {
       // loads newer than step s+1's: NPF-1 steps' worth while the queue is full, fewer (so wait for all) at the tail
-      if (s + NPF < s_end) wait_vmcnt<(NPF - 1) * (1 + MAXP)>();
+      if (s + NPF < s_end) wait_vmcnt<(NPF - 1) * (1 + MAXP) * LPI>();
       else wait_vmcnt<0>();
       commit(s + 1, slot_next, next_lo, next_hi);
     }
@@ -372,22 +435,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         if (x_lane) {
           const int er = p.w_shift >= 0 ? (e >> p.w_shift) : e / p.W;
           const size_t pixel = (size_t)(w_lo + er) * p.rmul + (size_t)(e - er * p.W) * p.cmul;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(xc + pixel * p.Cin + ci0 + chunk * 8);
+          const elem_t* src = xc + pixel * p.Cin + ci0 + chunk * 8;
+          Item it;
+#pragma unroll
+          for (int l = 0; l < LPI; ++l)
+            it.v[l] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) + 16 * l);
           const int row = w_lo + er, iw = e - er * p.W + p.pad;
           const int slot = p.stride == 1 ? iw : (iw & 1) * p.half + (iw >> 1);
-          *reinterpret_cast<u32x4*>(x_lds + (chunk >> 1) * plane_bytes + ((row & line_mask) * p.wslots + slot) * 32 +
-                                    (chunk & 1) * 16) = v;
+          put(x_lds + (chunk >> 1) * plane_bytes + ((row & line_mask) * p.wslots + slot) * 32 + (chunk & 1) * 16,
+              xpl_bytes, it);
         }
       }
       {  // gy tile of the first step
         const int qd = pix >> 2, q = pix & 3;
         const int gbase = T[qd * 4 + 0], ow0 = T[qd * 4 + 3];
-        u32x4 v = {0, 0, 0, 0};
-        if (gy_lane && gbase >= 0 && ow0 + q < p.Wo)
-          v = *reinterpret_cast<const u32x4*>(gc + (size_t)(gbase + q) * p.Cout + co0 + chunk * 8);
+        Item it;
+#pragma unroll
+        for (int l = 0; l < LPI; ++l) it.v[l] = u32x4{0, 0, 0, 0};
+        if (gy_lane && gbase >= 0 && ow0 + q < p.Wo) {
+          const elem_t* src = gc + (size_t)(gbase + q) * p.Cout + co0 + chunk * 8;
+#pragma unroll
+          for (int l = 0; l < LPI; ++l)
+            it.v[l] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) + 16 * l);
+        }
         if (chunk < TMT * 2)
-          *reinterpret_cast<u32x4*>(gy_lds + (s_begin & 1) * TMT * 1024 + (chunk >> 1) * 1024 + pix * 32 +
-                                    (chunk & 1) * 16) = v;
+          put(gy_lds + (s_begin & 1) * NPL * GYB + (chunk >> 1) * 1024 + pix * 32 + (chunk & 1) * 16, GYB, it);
       }
     }
     load_desc(s_begin);
@@ -478,15 +550,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-template <int TMT, int KS, int MAXP, int NPF, bool FAST>
+template <int TMT, int KS, int MAXP, int NPF, bool FAST, int NPL>
 int launch(const WgradParams& p, int Kc, hipStream_t st) {
-  size_t lds = 2 * TMT * 1024 + 4 * (size_t)(p.nlines + 1) * p.wslots * 32;
+  size_t lds = NPL * (2 * TMT * 1024 + 4 * (size_t)(p.nlines + 1) * p.wslots * 32);
   const size_t lds_epilogue = 4 * 16 * (16 * KS * KS + 4) * sizeof(float);  // LDS-transposed write-out
   if (KS > 1 && lds < lds_epilogue) lds = lds_epilogue;
   if (lds > 160 * 1024) return 3;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST, NPL>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
@@ -495,7 +567,7 @@ int launch(const WgradParams& p, int Kc, hipStream_t st) {
   q.ntiles = n_co_tiles * n_ci_tiles;
   q.total_blocks = q.ntiles * Kc * p.split;
   const int grid = (q.total_blocks + 7) / 8 * 8;
-  hipLaunchKernelGGL((conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST>), dim3(grid), dim3(256), lds, st, q);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST, NPL>), dim3(grid), dim3(256), lds, st, q);
   if (p.split > 1) {
     int gx = cdiv(p.numel, 256 * 4);
     if (gx > 1024) gx = 1024;
@@ -512,12 +584,13 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
                                  int accumulate, int Kc, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
                                  int ks, int stride, int pad, const int* table, int nsteps, int nlines, int wslots,
                                  int tmt, int split, float* scratch, int rmul, int cmul, int passes, int rows_r, int rows_off,
-                                 long x_client_stride, int cin_store, hipStream_t st) {
+                                 long x_client_stride, int cin_store, int npl, hipStream_t st) {
+  if (npl < 1 || npl > 3) return 8;
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || Cin % 16 || Cout % 16) return 1;
   if (nlines & (nlines - 1)) return 2;
   if (cin_store < 1 || cin_store > Cin) return 7;
   WgradParams p;
-  p.x = (const unsigned short*)x; p.gy = (const unsigned short*)gy; p.U = U; p.ld = ld; p.off = off;
+  p.x = x; p.gy = gy; p.U = U; p.ld = ld; p.off = off;
   p.coef = coef; p.table = table; p.accumulate = accumulate;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.stride = stride; p.pad = pad;
   p.nsteps = nsteps; p.nlines = nlines; p.wslots = wslots; p.half = wslots / 2;
@@ -537,13 +610,20 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
   while ((1 << p.lg_ho) < Ho) ++p.lg_ho;
   p.nquads = B * Ho * qpr;
   p.rows_r = rows_r; p.rows_off = rows_off; p.rows_last = B * H - 1;
-#define GO(T, K)                                                                        \
-  do {                                                                                  \
-    if (fast) return passes <= 1 ? launch<T, K, 1, 3, true>(p, Kc, st) : launch<T, K, 4, 1, true>(p, Kc, st); \
-    return passes <= 1 ? launch<T, K, 1, 2, false>(p, Kc, st) : launch<T, K, 4, 1, false>(p, Kc, st);           \
+#define GO2(T, K, N)                                                                         \
+  do {                                                                                       \
+    if (fast) return passes <= 1 ? launch<T, K, 1, 3, true, N>(p, Kc, st) : launch<T, K, 4, 1, true, N>(p, Kc, st); \
+    return passes <= 1 ? launch<T, K, 1, 2, false, N>(p, Kc, st) : launch<T, K, 4, 1, false, N>(p, Kc, st);           \
+  } while (0)
+#define GO(T, K)                  \
+  do {                            \
+    if (npl == 1) GO2(T, K, 1);   \
+    if (npl == 2) GO2(T, K, 2);   \
+    GO2(T, K, 3);                 \
   } while (0)
   if (ks == 3) { if (tmt == 4) GO(4, 3); if (tmt == 2) GO(2, 3); if (tmt == 1) GO(1, 3); }
   else { if (tmt == 4) GO(4, 1); if (tmt == 2) GO(2, 1); if (tmt == 1) GO(1, 1); }
 #undef GO
+#undef GO2
   return 5;
 }

@@ -27,11 +27,35 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   return *reinterpret_cast<unsigned short*>(&h);
 }
 
+// 8 consecutive channels of one pixel <-> 8 floats; T = unsigned short (bf16 bits, 16 B) or float (2 x 16 B)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<unsigned short>(const unsigned short* p, float (&v)[8]) {
+  const u16x8 t = *reinterpret_cast<const u16x8*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = bf2f(t[j]);
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+// stores the values rounded to T and returns them (as the next layer will read them) in v
+template <typename T> __device__ __forceinline__ void store8(T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void store8<unsigned short>(unsigned short* p, float (&v)[8]) {
+  u16x8 t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { t[j] = f2bf(v[j]); v[j] = bf2f(t[j]); }
+  *reinterpret_cast<u16x8*>(p) = t;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
 // partial[(c * nchunk + chunk) * C * 2 + ch * 2 + {0,1}]
 // MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g * xhat), g = gy gated by the ReLU bitmask (if any)
-template <int MODE>
-__global__ __launch_bounds__(TPB) void pcbn_reduce_kernel(const unsigned short* __restrict__ x,
-                                                          const unsigned short* __restrict__ gy,
+template <int MODE, typename T>
+__global__ __launch_bounds__(TPB) void pcbn_reduce_kernel(const T* __restrict__ x,
+                                                          const T* __restrict__ gy,
                                                           const unsigned char* __restrict__ mask,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int P, int C,
@@ -55,20 +79,22 @@ __global__ __launch_bounds__(TPB) void pcbn_reduce_kernel(const unsigned short* 
   const size_t base = (size_t)client * P * C + (size_t)cg * 8;
   for (int p = p0 + prow; p < p1; p += rows) {
     const size_t off = base + (size_t)p * C;
-    const u16x8 xv = *reinterpret_cast<const u16x8*>(x + off);
+    float xv[8];
+    load8<T>(x + off, xv);
     if (MODE == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float v = bf2f(xv[j]); a[j] += v; b[j] += v * v; }
+      for (int j = 0; j < 8; ++j) { const float v = xv[j]; a[j] += v; b[j] += v * v; }
     } else {
-      const u16x8 gv = *reinterpret_cast<const u16x8*>(gy + off);
+      float gv[8];
+      load8<T>(gy + off, gv);
       // one mask byte per lane: bit j = (output j of this lane's 8 channels was > 0 in the forward pass)
       const unsigned mb = mask != nullptr ? mask[off >> 3] : 0xFFu;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float g = bf2f(gv[j]);
+        float g = gv[j];
         if (!((mb >> j) & 1u)) g = 0.f;
         a[j] += g;
-        b[j] += g * (bf2f(xv[j]) - mu[j]) * is[j];
+        b[j] += g * (xv[j] - mu[j]) * is[j];
       }
     }
   }
@@ -108,11 +134,12 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_finalize_kernel(const float* __r
   scale[i] = g * is; shift[i] = b - (float)m * g * is;
 }
 
-__global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const unsigned short* __restrict__ x,
-                                                             const unsigned short* __restrict__ res,
+template <typename T>
+__global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const T* __restrict__ x,
+                                                             const T* __restrict__ res,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int P, int C, int relu,
-                                                             unsigned short* __restrict__ y,
+                                                             T* __restrict__ y,
                                                              unsigned char* __restrict__ mask) {
   const int client = blockIdx.y;
   const int lpp = C >> 3;
@@ -126,20 +153,20 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const unsigned shor
   for (int j = 0; j < 8; ++j) { sc[j] = scale[client * C + cg * 8 + j]; sh[j] = shift[client * C + cg * 8 + j]; }
   for (size_t v = (size_t)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (size_t)gridDim.x * TPB) {
     const size_t off = base + v * 8;
-    const u16x8 xv = *reinterpret_cast<const u16x8*>(x + off);
-    u16x8 rv = xv;
-    if (res != nullptr) rv = *reinterpret_cast<const u16x8*>(res + off);
-    u16x8 out;
-    unsigned mb = 0;
+    float xv[8], rv[8], out[8];
+    load8<T>(x + off, xv);
+    if (res != nullptr) load8<T>(res + off, rv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float val = bf2f(xv[j]) * sc[j] + sh[j];
-      if (res != nullptr) val += bf2f(rv[j]);
+      float val = xv[j] * sc[j] + sh[j];
+      if (res != nullptr) val += rv[j];
       if (relu) val = fmaxf(val, 0.f);
-      out[j] = f2bf(val);
-      mb |= (bf2f(out[j]) > 0.f ? 1u : 0u) << j;  // gate on the rounded value the next layer actually sees
+      out[j] = val;
     }
-    *reinterpret_cast<u16x8*>(y + off) = out;
+    store8<T>(y + off, out);
+    unsigned mb = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mb |= (out[j] > 0.f ? 1u : 0u) << j;  // gate on the value the next layer actually sees
     // ReLU gate for the backward pass, 1 bit per element instead of re-reading y (2 bytes per element)
     if (mask != nullptr) mask[off >> 3] = (unsigned char)mb;
   }
@@ -178,14 +205,15 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_kernel(const float* __r
   k_c[i] = ks * (mean[i] * invstd[i] * kc - kb);  // Cc
 }
 
-__global__ __launch_bounds__(TPB) void pcbn_bwd_apply_kernel(const unsigned short* __restrict__ x,
-                                                             const unsigned short* __restrict__ gy,
+template <typename T>
+__global__ __launch_bounds__(TPB) void pcbn_bwd_apply_kernel(const T* __restrict__ x,
+                                                             const T* __restrict__ gy,
                                                              const unsigned char* __restrict__ mask,
                                                              const float* __restrict__ k_a,
                                                              const float* __restrict__ k_bx,
                                                              const float* __restrict__ k_cc, int P, int C,
-                                                             unsigned short* __restrict__ dx,
-                                                             unsigned short* __restrict__ gres) {
+                                                             T* __restrict__ dx,
+                                                             T* __restrict__ gres) {
   const int client = blockIdx.y;
   const int lpp = C >> 3;
   const size_t nvec = (size_t)P * lpp;
@@ -199,48 +227,78 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_apply_kernel(const unsigned shor
   }
   for (size_t v = (size_t)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (size_t)gridDim.x * TPB) {
     const size_t off = base + v * 8;
-    const u16x8 xv = *reinterpret_cast<const u16x8*>(x + off);
-    const u16x8 gv = *reinterpret_cast<const u16x8*>(gy + off);
+    float xv[8], gv[8], o[8], r[8];
+    load8<T>(x + off, xv);
+    load8<T>(gy + off, gv);
     const unsigned mb = mask != nullptr ? mask[off >> 3] : 0xFFu;
-    u16x8 o, r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float g = bf2f(gv[j]);
+      float g = gv[j];
       if (!((mb >> j) & 1u)) g = 0.f;
-      o[j] = f2bf(ka[j] * g + kb[j] * bf2f(xv[j]) + kc[j]);
-      r[j] = f2bf(g);
+      o[j] = ka[j] * g + kb[j] * xv[j] + kc[j];
+      r[j] = g;
     }
-    *reinterpret_cast<u16x8*>(dx + off) = o;
-    if (gres != nullptr) *reinterpret_cast<u16x8*>(gres + off) = r;
+    store8<T>(dx + off, o);
+    if (gres != nullptr) store8<T>(gres + off, r);
   }
 }
 
-inline int chunk_pixels(int C) {
-  int p = 262144 / (C * 2);
+inline int chunk_pixels(int C, int esize = 2) {
+  int p = 262144 / (C * esize);
   if (p < 64) p = 64;
   return p;
 }
 
-}  // namespace
-
-BLADES_API int blades_pcbn_nchunk(int P, int C) { return cdiv(P, chunk_pixels(C)); }
-
-// workspace `partial`: Kc * nchunk * C * 2 floats.
-BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* gamma, const float* beta, int Kc,
-                                   int P, int C, float eps, int relu, float* partial, float* mean, float* invstd,
-                                   float* scale, float* shift, void* y, void* relu_mask, hipStream_t st) {
-  if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
-  const int ppc = chunk_pixels(C), nch = cdiv(P, ppc);
-  hipLaunchKernelGGL((pcbn_reduce_kernel<0>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st,
-                     (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, P, C, ppc, nch, partial);
+template <typename T>
+int pcbn_forward_t(const void* x, const void* res, const float* gamma, const float* beta, int Kc, int P, int C, float eps,
+                   int relu, float* partial, float* mean, float* invstd, float* scale, float* shift, void* y,
+                   void* relu_mask, hipStream_t st) {
+  const int ppc = chunk_pixels(C, sizeof(T)), nch = cdiv(P, ppc);
+  hipLaunchKernelGGL((pcbn_reduce_kernel<0, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
+                     (const T*)nullptr, nullptr, nullptr, nullptr, P, C, ppc, nch, partial);
   hipLaunchKernelGGL(pcbn_fwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
                      eps, gamma, beta, mean, invstd, scale, shift);
   int gx = cdiv((long)P * (C / 8), TPB);
   if (gx > 512) gx = 512;
-  hipLaunchKernelGGL(pcbn_fwd_apply_kernel, dim3(gx, Kc), dim3(TPB), 0, st, (const unsigned short*)x,
-                     (const unsigned short*)res, scale, shift, P, C, relu, (unsigned short*)y,
-                     (unsigned char*)relu_mask);
+  hipLaunchKernelGGL((pcbn_fwd_apply_kernel<T>), dim3(gx, Kc), dim3(TPB), 0, st, (const T*)x, (const T*)res, scale,
+                     shift, P, C, relu, (T*)y, (unsigned char*)relu_mask);
   return 0;
+}
+
+template <typename T>
+int pcbn_backward_t(const void* x, const void* gy, const void* relu_mask, const float* gamma, const float* mean,
+                    const float* invstd, int Kc, int P, int C, const float* coef, float* U, long ld, long off_gamma,
+                    long off_beta, int accumulate, float* partial, float* k_scale, float* k_b, float* k_c, void* dx,
+                    void* gres, hipStream_t st) {
+  const int ppc = chunk_pixels(C, sizeof(T)), nch = cdiv(P, ppc);
+  hipLaunchKernelGGL((pcbn_reduce_kernel<1, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
+                     (const T*)gy, (const unsigned char*)relu_mask, mean, invstd, P, C, ppc, nch, partial);
+  hipLaunchKernelGGL(pcbn_bwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
+                     gamma, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c);
+  int gx = cdiv((long)P * (C / 8), TPB);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL((pcbn_bwd_apply_kernel<T>), dim3(gx, Kc), dim3(TPB), 0, st, (const T*)x, (const T*)gy,
+                     (const unsigned char*)relu_mask, k_scale, k_b, k_c, P, C, (T*)dx, (T*)gres);
+  return 0;
+}
+
+}  // namespace
+
+// esize: bytes per activation element (2 = bf16, 4 = fp32)
+BLADES_API int blades_pcbn_nchunk(int P, int C, int esize) { return cdiv(P, chunk_pixels(C, esize)); }
+
+// workspace `partial`: Kc * nchunk * C * 2 floats.
+BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* gamma, const float* beta, int Kc,
+                                   int P, int C, float eps, int relu, float* partial, float* mean, float* invstd,
+                                   float* scale, float* shift, void* y, void* relu_mask, int esize, hipStream_t st) {
+  if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
+  if (esize == 4)
+    return pcbn_forward_t<float>(x, res, gamma, beta, Kc, P, C, eps, relu, partial, mean, invstd, scale, shift, y,
+                                 relu_mask, st);
+  if (esize == 2)
+    return pcbn_forward_t<unsigned short>(x, res, gamma, beta, Kc, P, C, eps, relu, partial, mean, invstd, scale,
+                                          shift, y, relu_mask, st);
+  return 2;
 }
 
 // workspace: partial (as forward), k_scale/k_b/k_c: Kc*C floats each.
@@ -248,18 +306,14 @@ BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* 
 BLADES_API int blades_pcbn_backward(const void* x, const void* gy, const void* relu_mask, const float* gamma,
                                     const float* mean, const float* invstd, int Kc, int P, int C, const float* coef,
                                     float* U, long ld, long off_gamma, long off_beta, int accumulate, float* partial,
-                                    float* k_scale, float* k_b, float* k_c, void* dx, void* gres, hipStream_t st) {
+                                    float* k_scale, float* k_b, float* k_c, void* dx, void* gres, int esize,
+                                    hipStream_t st) {
   if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
-  const int ppc = chunk_pixels(C), nch = cdiv(P, ppc);
-  hipLaunchKernelGGL((pcbn_reduce_kernel<1>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st,
-                     (const unsigned short*)x, (const unsigned short*)gy, (const unsigned char*)relu_mask, mean, invstd,
-                     P, C, ppc, nch, partial);
-  hipLaunchKernelGGL(pcbn_bwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
-                     gamma, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c);
-  int gx = cdiv((long)P * (C / 8), TPB);
-  if (gx > 512) gx = 512;
-  hipLaunchKernelGGL(pcbn_bwd_apply_kernel, dim3(gx, Kc), dim3(TPB), 0, st, (const unsigned short*)x,
-                     (const unsigned short*)gy, (const unsigned char*)relu_mask, k_scale, k_b, k_c, P, C,
-                     (unsigned short*)dx, (unsigned short*)gres);
-  return 0;
+  if (esize == 4)
+    return pcbn_backward_t<float>(x, gy, relu_mask, gamma, mean, invstd, Kc, P, C, coef, U, ld, off_gamma, off_beta,
+                                  accumulate, partial, k_scale, k_b, k_c, dx, gres, st);
+  if (esize == 2)
+    return pcbn_backward_t<unsigned short>(x, gy, relu_mask, gamma, mean, invstd, Kc, P, C, coef, U, ld, off_gamma,
+                                           off_beta, accumulate, partial, k_scale, k_b, k_c, dx, gres, st);
+  return 2;
 }

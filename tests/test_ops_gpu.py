@@ -201,13 +201,15 @@ def test_augment_matches_reference(dev):
 @pytest.mark.parametrize("Kc,B,C,H,relu,res", [(3, 4, 64, 8, True, False), (2, 8, 128, 4, True, True),
                                                (5, 2, 512, 4, False, False), (2, 16, 64, 32, True, True),
                                                (1, 64, 256, 8, False, True)])
-def test_pcbn_kernels(dev, Kc, B, C, H, relu, res):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pcbn_kernels(dev, Kc, B, C, H, relu, res, dtype):
     from blades_amd.engine import fused
     from blades_amd import ops
 
     h = ops._h()
     g = torch.Generator().manual_seed(1)
-    mk = lambda: (torch.randn(Kc * B, C, H, H, generator=g) * 1.5 + 0.3).to(dev).to(torch.bfloat16).contiguous(
+    f32 = dtype == torch.float32
+    mk = lambda: (torch.randn(Kc * B, C, H, H, generator=g) * 1.5 + 0.3).to(dev).to(dtype).contiguous(
         memory_format=torch.channels_last)
     x, r, gy = mk(), (mk() if res else None), mk()
     gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
@@ -223,42 +225,66 @@ def test_pcbn_kernels(dev, Kc, B, C, H, relu, res):
         gate = (pos << torch.arange(8, device=dev, dtype=torch.uint8)).sum(1).to(torch.uint8)
     torch.testing.assert_close(mean, mean2, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(invstd, invstd2, rtol=1e-3, atol=1e-4)
-    torch.testing.assert_close(y.float(), y2.float(), rtol=2e-2, atol=2e-2)
+    if f32:
+        torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-5)
+    else:
+        torch.testing.assert_close(y.float(), y2.float(), rtol=2e-2, atol=2e-2)
     D = 3 * C + 7
     U = torch.zeros(Kc, D, device=dev)
     coef = torch.tensor([(-1.0) ** i * (i + 1) for i in range(Kc)], device=dev)
     dx, gres = h.pcbn_backward(x, gy, gate if relu else None, gamma, mean2, invstd2, Kc, coef, U, 5, C + 6, False,
                                res and relu)
     dx2, gres2, dgamma, dbeta = fused._bn_backward_ref(x, gy, y2, gamma, mean2, invstd2, Kc, relu, res and relu)
-    torch.testing.assert_close(dx.float(), dx2.float(), rtol=3e-2, atol=3e-2)
     scale = max(1.0, float(dgamma.abs().max()))
-    torch.testing.assert_close(U[:, 5: 5 + C], dgamma * coef[:, None], rtol=1e-3, atol=1e-3 * scale)
-    torch.testing.assert_close(U[:, C + 6: 2 * C + 6], dbeta * coef[:, None], rtol=1e-3, atol=1e-3 * scale)
+    if f32:
+        torch.testing.assert_close(dx, dx2, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(U[:, 5: 5 + C], dgamma * coef[:, None], rtol=1e-4, atol=1e-5 * scale)
+        torch.testing.assert_close(U[:, C + 6: 2 * C + 6], dbeta * coef[:, None], rtol=1e-4, atol=1e-5 * scale)
+    else:
+        torch.testing.assert_close(dx.float(), dx2.float(), rtol=3e-2, atol=3e-2)
+        torch.testing.assert_close(U[:, 5: 5 + C], dgamma * coef[:, None], rtol=1e-3, atol=1e-3 * scale)
+        torch.testing.assert_close(U[:, C + 6: 2 * C + 6], dbeta * coef[:, None], rtol=1e-3, atol=1e-3 * scale)
     if res and relu:
         torch.testing.assert_close(gres.float(), gres2.float(), rtol=1e-2, atol=1e-2)
     assert float(U[:, :5].abs().sum()) == 0 and float(U[:, 2 * C + 6:].abs().sum()) == 0
 
 
-def test_fused_engine_gpu_matches_fp32_reference(dev, tmp_path):
-    """bf16 fused executor on the GPU vs the fp32 vectorised path on the CPU."""
+@pytest.mark.parametrize("amp", ["fp32", "bf16x3", "bf16"])
+def test_fused_engine_gpu_matches_fp32_reference(dev, tmp_path, amp):
+    """One full fused ResNet-10 round on the GPU (own forward / data-gradient / weight-gradient convolution
+    kernels, per-client BatchNorm kernels) against the fp32 oracle on the CPU, row by row.  The default fp32 mode
+    (exact 3 x bf16 operand split, fp32 accumulation) must agree to fp32 tolerance; bf16 only in direction/size."""
     from tests.test_engine_paths import build, one_round_updates
 
     a = build(str(tmp_path), "resnet", "fused")
     b = build(str(tmp_path), "resnet", "fused")
-    # move a to the GPU with bf16 compute
     import copy
-    from blades_amd.algorithms.fedavg import FedavgConfig
 
     cfg = copy.deepcopy(a.config)
     cfg._is_frozen = False
-    cfg.device, cfg.amp_dtype = "cuda", "bf16"
+    cfg.device, cfg.amp_dtype = "cuda", amp
     g = cfg.build()
+    assert g.engine.compute_dtype == amp
     g.server.theta.copy_(b.server.theta.to(dev))
     Ug, _ = one_round_updates(g)
     Ub, _ = one_round_updates(b)
-    cos = torch.nn.functional.cosine_similarity(Ug.cpu(), Ub, dim=1)
+    d = Ug.cpu() - Ub
+    rel = d.norm(dim=1) / Ub.norm(dim=1)
+    if amp == "fp32":
+        # Element by element at rtol 1e-3 / atol 1e-5.  The only tolerated deviations are ReLU gates that sit on
+        # zero: a pre-activation of ~1e-7 can round to either side in two correct fp32 implementations, which
+        # changes that one pixel's gradient contribution (a few hundred weights of one row).  Measured
+        # (tools/probes/fp32_round_probe.py): rows without such an event agree to 2e-6 in relative L2, 0 elements
+        # out of tolerance; one event costs ~1300 of 29.4 M elements.
+        bad = d.abs() > 1e-5 + 1e-3 * Ub.abs()
+        assert int(bad.sum()) <= 1e-4 * bad.numel(), int(bad.sum())
+        assert float(rel.median()) < 1e-5 and float(rel.max()) < 5e-3, rel
+        return
+    cos = torch.nn.functional.cosine_similarity(Ug.cpu().double(), Ub.double(), dim=1)
+    if amp == "bf16x3":
+        assert float(cos.min()) > 0.9999 and float(rel.max()) < 3e-2, (cos, rel)
+        return
     assert float(cos.min()) > 0.98, cos
-    rel = (Ug.cpu() - Ub).norm(dim=1) / Ub.norm(dim=1)
     assert float(rel.max()) < 0.2, rel
 
 
@@ -275,23 +301,35 @@ def test_fused_engine_gpu_matches_fp32_reference(dev, tmp_path):
     (1, 5, 16, 48, 11, 3, 1, 1),
     (3, 4, 3, 64, 32, 3, 1, 1),
     (2, 4, 1, 32, 28, 3, 1, 1),
+    # headline-sized reductions: batch 64, odd client counts, block counts that are not multiples of 8
+    (37, 64, 64, 64, 32, 3, 1, 1),
+    (5, 64, 256, 512, 8, 1, 2, 0),
+    (9, 64, 128, 256, 16, 3, 2, 1),
 ])
-def test_conv_wgrad_kernel(dev, Kc, B, Cin, Cout, H, ks, stride, pad):
+@pytest.mark.parametrize("npl", [1, 3, 2])
+def test_conv_wgrad_kernel(dev, Kc, B, Cin, Cout, H, ks, stride, pad, npl):
     import torch.nn.functional as F
     from blades_amd import ops
 
     h = ops._h()
     g = torch.Generator().manual_seed(2)
-    x = torch.randn(Kc * B, Cin, H, H, generator=g).to(dev).to(torch.bfloat16).contiguous(
-        memory_format=torch.channels_last)
+    dt = torch.bfloat16 if npl == 1 else torch.float32
+    x = torch.randn(Kc * B, Cin, H, H, generator=g).to(dev).to(dt).contiguous(memory_format=torch.channels_last)
     Ho = (H + 2 * pad - ks) // stride + 1
-    gy = torch.randn(Kc * B, Cout, Ho, Ho, generator=g).to(dev).to(torch.bfloat16).contiguous(
-        memory_format=torch.channels_last)
+    gy = torch.randn(Kc * B, Cout, Ho, Ho, generator=g).to(dev).to(dt).contiguous(memory_format=torch.channels_last)
     n = Cout * Cin * ks * ks
     U = torch.full((Kc, n + 11), 7.0, device=dev)
-    coef = torch.tensor([(-0.5) ** i for i in range(Kc)], device=dev)
+    coef = torch.tensor([(-0.5) ** (i % 7) for i in range(Kc)], device=dev)
     assert h.conv_wgrad_supported(x, gy, (ks, ks), (stride, stride), (pad, pad), (1, 1))
-    assert h.conv_wgrad_(x, gy, Kc, U, 5, coef, False, ks, stride, pad)
+    xk, gk, sk = x, gy, stride
+    if not h.conv_wgrad_(x, gy, Kc, U, 5, coef, False, ks, stride, pad, npl):
+        # split planes of a strided 3x3 window do not fit in LDS: the engine (PCConv2d.wgrad_hip) spreads gy onto
+        # the input grid and runs the stride-1 kernel
+        assert npl > 1 and stride == 2 and ks == 3
+        gk = torch.empty((Kc * B, Cout, 2 * Ho, 2 * Ho), dtype=dt, device=dev, memory_format=torch.channels_last).zero_()
+        gk[:, :, ::2, ::2] = gy
+        sk = 1
+        assert h.conv_wgrad_(xk, gk, Kc, U, 5, coef, False, ks, sk, pad, npl)
     # fp32 reference on the bf16-rounded inputs
     ref = torch.empty(Kc, Cout, Cin, ks, ks, device=dev)
     w = torch.zeros(Cout, Cin, ks, ks, device=dev)
@@ -301,11 +339,47 @@ def test_conv_wgrad_kernel(dev, Kc, B, Cin, Cout, H, ks, stride, pad):
                                                      1, [False, True, False])[1] * coef[c]
     got = U[:, 5:5 + n].reshape(Kc, Cout, Cin, ks, ks)
     scale = float(ref.abs().max())
-    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3 * scale)
+    # bf16: inputs are rounded already, only accumulation order differs; fp32 planes: 3 = fp32 grade, 2 = ~2^-17
+    tol = {1: 2e-3, 3: 2e-5, 2: 2e-4}[npl]
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol * scale)
     assert float((U[:, :5] - 7).abs().sum()) == 0 and float((U[:, 5 + n:] - 7).abs().sum()) == 0
     # accumulate mode
-    assert h.conv_wgrad_(x, gy, Kc, U, 5, coef, True, ks, stride, pad)
-    torch.testing.assert_close(U[:, 5:5 + n].reshape(Kc, Cout, Cin, ks, ks), 2 * ref, rtol=2e-3, atol=4e-3 * scale)
+    assert h.conv_wgrad_(xk, gk, Kc, U, 5, coef, True, ks, sk, pad, npl)
+    torch.testing.assert_close(U[:, 5:5 + n].reshape(Kc, Cout, Cin, ks, ks), 2 * ref, rtol=tol, atol=2 * tol * scale)
+
+
+@pytest.mark.parametrize("N,Ci,H,W,Co,k,s,p", [
+    (4, 64, 32, 32, 64, 3, 1, 1), (3, 64, 32, 32, 128, 3, 2, 1), (3, 64, 32, 32, 128, 1, 2, 0),
+    (5, 128, 16, 16, 128, 3, 1, 1), (9, 256, 8, 8, 512, 3, 2, 1), (37, 512, 4, 4, 512, 3, 1, 1),
+    (6, 3, 32, 32, 64, 3, 1, 1), (7, 1, 28, 28, 32, 3, 1, 1), (7, 32, 14, 14, 64, 3, 1, 0),
+    (2, 48, 13, 11, 40, 3, 1, 1), (2, 20, 9, 9, 24, 5, 1, 2), (2, 16, 15, 15, 16, 3, 2, 1),
+    (2, 16, 12, 12, 16, 3, 3, 0),
+])
+@pytest.mark.parametrize("npl", [3, 2, 1])
+def test_conv_igemm_kernel(dev, N, Ci, H, W, Co, k, s, p, npl):
+    """Own forward / data-gradient convolution (ops/csrc/conv_igemm.hip) against an fp64 convolution."""
+    import torch.nn.functional as F
+    from blades_amd import ops
+
+    h = ops._h()
+    g = torch.Generator().manual_seed(N * 1000 + Ci)
+    dt = torch.bfloat16 if npl == 1 else torch.float32
+    x = torch.randn(N, Ci, H, W, generator=g).to(dt)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = (w.to(dt) if npl == 1 else w).double()
+    y_ref = F.conv2d(xr, wr, b.double(), s, p)
+    gy = torch.randn(y_ref.shape, generator=g).to(dt)
+    dx_ref, = torch.autograd.grad(y_ref, xr, gy.double())
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    gyd = gy.to(dev).contiguous(memory_format=torch.channels_last)
+    assert h.conv_igemm_supported(xd, w.to(dev), (s, s), (p, p), (1, 1), npl)
+    y = h.conv_forward(xd, w.to(dev), b.to(dev), s, p, npl)
+    dx = h.conv_dgrad(gyd, w.to(dev), (H, W), s, p, npl)
+    tol = {3: 1e-5, 2: 5e-5, 1: 2e-2}[npl]
+    torch.testing.assert_close(y.double().cpu(), y_ref.detach(), rtol=tol, atol=tol * float(y_ref.abs().max()))
+    torch.testing.assert_close(dx.double().cpu(), dx_ref, rtol=tol, atol=tol * float(dx_ref.abs().max()))
 
 
 @pytest.mark.parametrize("N,C", [(1, 10), (300, 10), (1000, 10), (257, 100), (64, 3)])
