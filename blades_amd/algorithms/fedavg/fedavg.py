@@ -330,8 +330,7 @@ class Fedavg(Algorithm):
         super().__setstate__(state)
         if "server" in state:
             self.server.load_state_dict(state["server"])
-            if state.get("world_size", 1) == self.rt.world_size:
-                self.engine.load_state_dict(state["engine"])
+            self.engine.load_state_dict(state["engine"])  # keyed by client uid: any world size
             self.adversary.load_state_dict(state.get("adversary", {}))
             self._counters.update(state.get("counters", {}))
             torch.set_rng_state(state["torch_rng"])

@@ -105,11 +105,19 @@ class DeviceSampler:
             if done.any():
                 self._reshuffle(rows[done])
 
+    # Checkpoint state is per *client uid*, not per local row: permutations are a pure function of
+    # (seed, uid, epoch), so (cursor, epoch) is all there is to save, and a run can resume on a different
+    # number of ranks (each rank picks the uids it owns).
     def state_dict(self):
-        return {"cursor": self.cursor.copy(), "perm": self.perm.cpu(), "epoch": self.epoch.copy()}
+        return {int(u): (int(c), int(e)) for u, c, e in zip(self.uids, self.cursor, self.epoch)}
 
     def load_state_dict(self, s):
-        self.cursor = np.asarray(s["cursor"]).copy()
-        self.cursor_t.copy_(torch.as_tensor(self.cursor))
-        self.perm.copy_(s["perm"].to(self.device))
-        self.epoch = np.asarray(s["epoch"]).copy()
+        rows = np.array([r for r, u in enumerate(self.uids) if int(u) in s], dtype=np.int64)
+        if len(rows) == 0:
+            return
+        st = [s[int(self.uids[r])] for r in rows]
+        self.epoch[rows] = np.array([e for _, e in st], dtype=np.int64) - 1
+        self._reshuffle(rows)  # regenerates the permutation of the saved epoch (and bumps epoch back)
+        self.cursor[rows] = np.array([c for c, _ in st], dtype=np.int64)
+        self.cursor_t[torch.as_tensor(rows, device=self.device)] = torch.as_tensor(self.cursor[rows],
+                                                                                   device=self.device)

@@ -278,11 +278,12 @@ class ClientEngine:
         """[Kc, N_UNIFORMS] uniforms keyed by (seed, client uid, augmentation call counter)."""
         from blades_amd.ops.reference import _philox4x32
 
-        self._aug_calls = getattr(self, "_aug_calls", 0) + 1
+        # keyed by (seed, client uid, round, local step): independent of chunking and of the number of ranks
+        batch_no = self.round * self.nb + getattr(self, "_local_step", 0) + 1
         n = tf.N_UNIFORMS
         uid = torch.as_tensor(self._train_uids[srows], dtype=torch.int64).unsqueeze(1).expand(-1, n)
         j = torch.arange(n, dtype=torch.int64).unsqueeze(0).expand(len(srows), -1)
-        call = torch.full_like(j, self._aug_calls & 0xFFFFFFFF)
+        call = torch.full_like(j, batch_no & 0xFFFFFFFF)
         sd = self.seed * 104729 + 3
         w = _philox4x32(j, uid & 0xFFFFFFFF, call, torch.full_like(j, 11), sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF)
         return (w[0] >> 8).float() * (1.0 / 16777216.0)
@@ -380,6 +381,7 @@ class ClientEngine:
         return ent["losses"]
 
     def _train_chunk_fedsgd(self, theta, rows, srows):
+        self._local_step = 0
         if self._graphs_wanted():
             losses = self._graphed_chunk(rows, srows)
             if losses is not None:
@@ -437,6 +439,7 @@ class ClientEngine:
             Mv = W  # unused
         loss_acc = torch.zeros(Kc, device=self.device)
         for step in range(self.nb):
+            self._local_step = step
             X, Y = self._fetch_batch(srows, flip)
             if self.grouped is not None:
                 losses = self.grouped.run(W, X, Y, G)
@@ -743,13 +746,33 @@ class ClientEngine:
         return out
 
     # -- checkpoint -------------------------------------------------------
+    # Engine state is global and keyed by client uid (sampler cursors/epochs, per-client momentum rows): rank 0
+    # collects every rank's share, and on load each rank takes the uids it owns — also when the run resumes on
+    # a different number of ranks.  (Collective: call on every rank.)
     def state_dict(self):
-        return {"sampler": self.sampler.state_dict(), "aug_calls": getattr(self, "_aug_calls", 0),
-                "M": None if self.M is None else self.M.cpu(), "mom_init": self._mom_init, "round": self.round}
+        local = {"sampler": self.sampler.state_dict(),
+                 "M": None if self.M is None else {int(u): self.M[k].cpu() for k, u in enumerate(self._train_uids)}}
+        shares = [local]
+        if self.ctx.distributed:
+            shares = [None] * self.rt.world_size if self.rt.rank == 0 else None
+            dist.gather_object(local, shares, dst=0)
+            shares = shares or [local]
+        sampler, M = {}, None
+        for sh in shares:
+            sampler.update(sh["sampler"])
+            if sh["M"] is not None:
+                M = M or {}
+                M.update(sh["M"])
+        return {"sampler": sampler, "M": M, "mom_init": self._mom_init, "round": self.round}
 
     def load_state_dict(self, s):
         self.sampler.load_state_dict(s["sampler"])
-        self._aug_calls = s.get("aug_calls", 0)
-        self.M = None if s["M"] is None else s["M"].to(self.device)
+        self.M = None
+        if s.get("M") is not None and len(self._train_uids):
+            self.M = torch.zeros(len(self._train_rows), self.D, device=self.device)
+            for k, u in enumerate(self._train_uids):
+                row = s["M"].get(int(u))
+                if row is not None:
+                    self.M[k].copy_(row.to(self.device))
         self._mom_init = s["mom_init"]
         self.round = s["round"]

@@ -22,7 +22,7 @@ def main():
                                  "use_cache": False, "synthetic": True})
            .training(global_model=spec.get("model", "mlp"),
                      server_config={"aggregator": spec["agg"], "optimizer": {"lr": 0.5, "momentum": spec.get("smom", 0.0)}})
-           .client(client_config={"lr": 0.5, "momentum": 0.0, "num_batch_per_round": spec.get("nb", 1)})
+           .client(client_config={"lr": 0.5, "momentum": spec.get("cmom", 0.0), "num_batch_per_round": spec.get("nb", 1)})
            .adversary(num_malicious_clients=spec["f"], adversary_config=spec["adv"])
            .evaluation(evaluation_interval=spec["rounds"])
            .engine(clients_per_chunk=3, amp_dtype=None, device="cpu"))
@@ -35,6 +35,8 @@ def main():
         for mod in m.modules():
             if isinstance(mod, torch.nn.modules.dropout._DropoutNd):
                 mod.p = 0.0
+    if spec.get("resume"):
+        algo.load_checkpoint(spec["resume"])
     last = None
     for _ in range(spec["rounds"]):
         last = algo.train()

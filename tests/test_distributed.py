@@ -94,3 +94,19 @@ def test_checkpoint_gathers_column_sharded_aggregator_state(tmp_path):
     assert m1.shape == m2.shape and m1.numel() == 136074  # full MLP width, not one rank's shard
     torch.testing.assert_close(m2, m1, rtol=1e-3, atol=1e-5)
     assert "config" in states[2]
+
+
+def test_multi_rank_resume_equals_straight_run(tmp_path):
+    """2 rounds + checkpoint + 2 resumed rounds == 4 straight rounds, with uneven shards (7 clients on 2 ranks),
+    per-client momentum and several batches per epoch — and the checkpoint of a 2-rank job resumes on 3 ranks:
+    sampler cursors / epochs and momentum rows are stored per client uid, not per local row."""
+    spec = {"K": 7, "f": 1, "agg": {"type": "Median"}, "adv": {"type": "blades.adversaries.ALIEAdversary"},
+            "root": str(tmp_path), "smom": 0.9, "cmom": 0.9}
+    straight = run(2, dict(spec, rounds=4), str(tmp_path / "s.pt"))
+    ck = tmp_path / "ck"
+    ck.mkdir()
+    run(2, dict(spec, rounds=2, ckpt=str(ck)), str(tmp_path / "a.pt"))
+    for world in (2, 3, 1):
+        got = run(world, dict(spec, rounds=2, resume=str(ck)), str(tmp_path / f"r{world}.pt"))
+        torch.testing.assert_close(got["theta"], straight["theta"], rtol=1e-3, atol=1e-4)
+        assert abs(got["train_loss"] - straight["train_loss"]) < 1e-4
