@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--samples-per-client", type=int, default=128)
     ap.add_argument("--local-steps", type=int, default=1, help="client SGD steps per round (1 = FedSGD headline)")
     ap.add_argument("--cpu", action="store_true", help="debug: run on CPU/gloo")
+    ap.add_argument("--layout", default="alltoall", choices=["alltoall", "allgather"],
+                    help="multi-GPU update-matrix layout: D-sharded aggregation after an all-to-all (default) or "
+                         "every rank gathers the full matrix (BASELINE config #5)")
     ap.add_argument("--torch-profile", default=None,
                     help="after the timed rounds, run one more under torch.profiler and write the op table here")
     args = ap.parse_args()
@@ -95,7 +98,7 @@ def main():
            .adversary(num_malicious_clients=f,
                       adversary_config={"type": f"blades.adversaries.{args.adversary}"})
            .evaluation(evaluation_interval=0)
-           .engine(clients_per_chunk=chunk, amp_dtype=args.amp))
+           .engine(clients_per_chunk=chunk, amp_dtype=args.amp, update_layout=args.layout))
     algo = cfg.build()
 
     def sync():
@@ -169,12 +172,16 @@ def main():
                 "model": args.model, "dataset": args.dataset, "num_clients": K, "num_malicious": f,
                 "adversary": args.adversary, "aggregator": args.aggregator, "client_batch": args.batch,
                 "global_batch": (K - f) * args.batch, "local_steps": args.local_steps, "update_dim": algo.engine.D,
-                "parallelism": f"clients sharded over {world} GPU(s); all-to-all to D-sharded aggregation",
+                "parallelism": (f"clients sharded over {world} GPU(s); all-to-all to D-sharded aggregation"
+                                if args.layout == "alltoall" or world == 1 else
+                                f"clients sharded over {world} GPU(s); all-gather of the full update matrix, "
+                                "replicated aggregation"),
             },
             "client_updates_per_sec": round(value * (K - f), 2),
             "samples_per_sec": round(value * (K - f) * args.batch, 1),
             "phase_ms": {k: round(v, 3) for k, v in timers.items()},
             "train_loss": last.get("train_loss") if last else None,
+            "comm_bytes": last.get("comm_bytes") if last else None,
             "clients_per_chunk": algo.engine.chunk,
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if rt.device.type == "cuda" else None,
         }

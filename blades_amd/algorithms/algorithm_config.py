@@ -64,6 +64,10 @@ class AlgorithmConfig:
         # MI355X engine knobs
         self.execution_mode = "auto"
         self.clients_per_chunk = "auto"  # int, or "auto" (engine/trainer.py picks per device and batch size)
+        # how the update matrix reaches the aggregator on several ranks: "alltoall" (row shard -> column shard,
+        # aggregation sharded over D) or "allgather" (every rank receives the full [K, D] matrix and aggregates
+        # replicated — BASELINE config #5; 8x the bytes of the all-to-all on 8 ranks)
+        self.update_layout = "alltoall"
         self.amp_dtype = "auto"
         self.device = "auto"
         self.nan_guard = True
@@ -113,9 +117,11 @@ class AlgorithmConfig:
         return self
 
     def engine(self, *, execution_mode=NotProvided, clients_per_chunk=NotProvided, amp_dtype=NotProvided,
-               device=NotProvided):
+               device=NotProvided, update_layout=NotProvided):
+        if update_layout is not NotProvided and update_layout not in ("alltoall", "allgather"):
+            raise ValueError(f"update_layout must be 'alltoall' or 'allgather', got {update_layout!r}")
         for k, v in (("execution_mode", execution_mode), ("clients_per_chunk", clients_per_chunk),
-                     ("amp_dtype", amp_dtype), ("device", device)):
+                     ("amp_dtype", amp_dtype), ("device", device), ("update_layout", update_layout)):
             if v is not NotProvided:
                 setattr(self, k, v)
         return self

@@ -118,9 +118,18 @@ class Fedavg(Algorithm):
 
         from blades_amd.parallel.context import ShardContext
 
-        ctx = ShardContext(d_total=0, world_size=self.rt.world_size, rank=self.rt.rank)
+        # "allgather" layout: every rank holds the whole update matrix and the whole theta and aggregates
+        # replicated, so the server / aggregators / adversaries see a non-distributed context
+        self.update_layout = getattr(config, "update_layout", "alltoall") if self.rt.world_size > 1 else "alltoall"
+        replicated = self.update_layout == "allgather"
+        ctx = ShardContext(d_total=0, world_size=1 if replicated else self.rt.world_size,
+                           rank=0 if replicated else self.rt.rank)
         self.server = config.get_server_config().build(self.device, ctx=ctx)
         self.ctx = self.server.ctx
+        if replicated:
+            import torch.distributed as dist
+
+            dist.broadcast(self.server.theta, src=0)  # identical start on every rank
 
         self.worker_group = self._setup_worker_group()
         self._setup_dataset()
@@ -139,7 +148,7 @@ class Fedavg(Algorithm):
             client_lr=ccfg.lr, client_momentum=ccfg.momentum, num_batch_per_round=ccfg.num_batch_per_round,
             batch_size=self._dataset.train_bs, seed=config.seed, clients_per_chunk=config.clients_per_chunk,
             amp_dtype=config.amp_dtype, execution_mode=config.execution_mode,
-            num_classes=dc.get("num_classes"))
+            num_classes=dc.get("num_classes"), update_layout=self.update_layout)
         self._malicious_flags = [bool(c.is_malicious) for c in clients]
         self._benign_mask = self.engine.row_mask([not m for m in self._malicious_flags])
         self.num_benign = int(sum(1 for m in self._malicious_flags if not m))  # host copy: no sync to ask
@@ -240,7 +249,8 @@ class Fedavg(Algorithm):
         results["timers"].update({k: v for k, v in self.engine.timers.items()})
         # bytes this rank moved over RCCL this round (update-matrix exchange / small all-reduces), SURVEY §5.5
         cs = self.ctx.stats
-        results["comm_bytes"] = {"alltoall": int(cs.get("alltoall_bytes", 0)),
+        results["comm_bytes"] = {"alltoall": int(self.engine.ctx.stats.get("alltoall_bytes", 0)),
+                                 "allgather": int(self.engine.ctx.stats.get("allgather_bytes", 0)),
                                  "allreduce": int(cs.get("allreduce_bytes", 0)) - self._allreduce_bytes_seen}
         self._allreduce_bytes_seen = int(cs.get("allreduce_bytes", 0))
         info = getattr(self.server.aggregator, "last_info", None)

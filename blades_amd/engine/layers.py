@@ -57,3 +57,105 @@ def make_engine_model(model: nn.Module) -> nn.Module:
 
     swap(tmpl)
     return tmpl
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Client-keyed dropout.  torch's dropout draws from the process RNG, so the masks a client sees would depend on the
+# rank it is trained on, on chunking and on the execution path.  The engine templates use masks that are a
+# counter-based function of (seed, client uid, round / local step, layer) instead: 1, 2 or 8 ranks — fused,
+# grouped or vmap path — train every client with the same masks (reference: nn.Dropout in
+# fllib/models/mnist/mlp.py, Dropout2d in fllib/models/fashionmnist/cnn.py, DropPath in cctnets).
+class DropContext:
+    """Which clients the batch in flight belongs to; shared by every ``ClientDropout`` of an engine."""
+
+    def __init__(self, seed: int, device):
+        self.seed = int(seed) * 1000003 + 17
+        self.device = device
+        self.layout = "major"       # "major": rows are [Kc*B, ...] client-major; "inner": [B, Kc*C, ...] (grouped
+        self.uids = None            # executor); "single": one client's [B, ...] batch (vmap), uid = 0-dim tensor
+        self.Kc = 0
+        self.tag = torch.zeros(1, dtype=torch.int64, device=device)  # round * nb + step, on the device: a captured
+        self.enabled = True                                          # HIP graph reads the current value
+
+    def set(self, uids: torch.Tensor, layout: str):
+        self.uids, self.layout, self.Kc = uids, layout, (int(uids.numel()) if uids.dim() else 1)
+
+    def set_tag(self, value: int):
+        self.tag.fill_(int(value))
+
+
+class ClientDropout(nn.Module):
+    """kind "elem": nn.Dropout; "channel": nn.Dropout2d (whole channels; on a 2-D input every element, as torch
+    does); "sample": DropPath (whole samples)."""
+
+    def __init__(self, p: float, kind: str, layer: int, ctx: DropContext):
+        super().__init__()
+        self.p, self.kind, self.layer, self.ctx = float(p), kind, int(layer), ctx
+
+    def extra_repr(self):
+        return f"p={self.p}, kind={self.kind}, layer={self.layer}"
+
+    def forward(self, x):
+        ctx = self.ctx
+        if not self.training or self.p <= 0.0 or not ctx.enabled or ctx.uids is None:
+            return x
+        from blades_amd import ops
+
+        lay, Kc = ctx.layout, ctx.Kc
+        if lay == "single":
+            B = x.shape[0]
+            keep = 1 if self.kind == "sample" else (2 if self.kind == "channel" and x.dim() > 2 else x.dim())
+            n = 1
+            for d in x.shape[:keep]:
+                n *= int(d)
+            m = ops.client_dropout_mult(ctx.uids, n, ctx.seed, ctx.tag, self.layer, self.p)
+            return x * m.reshape(*x.shape[:keep], *([1] * (x.dim() - keep))).to(x.dtype)
+        if lay == "major":
+            B = x.shape[0] // Kc
+            keep = 1 if self.kind == "sample" else (2 if self.kind == "channel" and x.dim() > 2 else x.dim())
+            per = 1
+            for d in x.shape[1:keep]:
+                per *= int(d)
+            m = ops.client_dropout_mult(ctx.uids, B * per, ctx.seed, ctx.tag, self.layer, self.p)
+            return x * m.reshape(*x.shape[:keep], *([1] * (x.dim() - keep))).to(x.dtype)
+        # "inner": x is [B, Kc*C, ...] with the client index outermost inside dim 1
+        B, C = x.shape[0], x.shape[1] // Kc
+        if self.kind == "sample":
+            m = ops.client_dropout_mult(ctx.uids, B, ctx.seed, ctx.tag, self.layer, self.p)  # [Kc, B]
+            m = m.t().reshape(B, Kc, 1).expand(B, Kc, C).reshape(B, Kc * C, *([1] * (x.dim() - 2)))
+            return x * m.to(x.dtype)
+        keep = 2 if self.kind == "channel" and x.dim() > 2 else x.dim()
+        per = C
+        for d in x.shape[2:keep]:
+            per *= int(d)
+        m = ops.client_dropout_mult(ctx.uids, B * per, ctx.seed, ctx.tag, self.layer, self.p)  # [Kc, B*per]
+        m = m.reshape(Kc, B, C, *x.shape[2:keep]).transpose(0, 1).reshape(B, Kc * C, *x.shape[2:keep])
+        return x * m.reshape(*m.shape, *([1] * (x.dim() - keep))).to(x.dtype)
+
+
+def swap_dropout(root: nn.Module, ctx: DropContext) -> nn.Module:
+    """Replaces every dropout-like leaf of ``root`` (in place) by a ``ClientDropout``; layer numbers follow the
+    module order, which is the same in every structural copy of a model."""
+    from blades_amd.models.cctnets.layers import DropPath
+
+    counter = [0]
+
+    def visit(mod):
+        for name, child in list(mod.named_children()):
+            kind = None
+            if isinstance(child, (nn.Dropout2d, nn.Dropout3d, nn.Dropout1d)):
+                kind = "channel"
+            elif isinstance(child, (nn.Dropout, nn.AlphaDropout)):
+                kind = "elem"
+            elif isinstance(child, DropPath):
+                kind = "sample"
+            if kind is not None:
+                setattr(mod, name, ClientDropout(child.p, kind, counter[0], ctx))
+                counter[0] += 1
+            elif not isinstance(child, ClientDropout):
+                visit(child)
+
+    holder = nn.Module()
+    holder.root = root
+    visit(holder)
+    return holder.root

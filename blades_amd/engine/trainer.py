@@ -35,7 +35,7 @@ from torch.func import functional_call, grad_and_value, vmap
 from blades_amd import ops
 from blades_amd.constants import CLIENT_UPDATE
 from blades_amd.parallel.context import ShardContext, padded_width
-from .layers import make_engine_model
+from .layers import DropContext, make_engine_model, swap_dropout
 from .plan import RowPlan, make_plan
 from .sampler import DeviceSampler
 
@@ -61,9 +61,10 @@ class ClientEngine:
     def __init__(self, *, task, dataset, clients: list, runtime, client_lr: float, client_momentum: float,
                  num_batch_per_round: int, batch_size: int, seed: int = 0, clients_per_chunk="auto",
                  amp_dtype="auto", execution_mode: str = "auto", num_classes: Optional[int] = None,
-                 eval_clients_per_chunk: Optional[int] = None):
+                 eval_clients_per_chunk: Optional[int] = None, update_layout: str = "alltoall"):
         self.task = task
-        self.model = make_engine_model(task.model)
+        self.drop_ctx = DropContext(seed, runtime.device)
+        self.model = swap_dropout(make_engine_model(task.model), self.drop_ctx)
         self.dataset = dataset
         self.clients = clients
         self.rt = runtime
@@ -138,10 +139,19 @@ class ClientEngine:
         # unpadded D: rows that start float4-aligned are what the streaming kernels' vector paths need
         # (Mean over 1000 x 11.2 M: 7.5 ms with aligned rows, 31 ms without).
         ld = padded_width(self.Dpad, 1)
-        self._U_store = torch.zeros(self.Kloc, ld, dtype=torch.float32, device=self.device)
-        self.U_row = self._U_store[:, : self.Dpad]
-        self.U_col = self.U_row if G == 1 else torch.zeros(self.K, self.Dl, dtype=torch.float32,
-                                                            device=self.device)
+        self.layout = update_layout if G > 1 else "alltoall"
+        if self.layout == "allgather":
+            # the full [K, D] matrix lives on every rank; this rank's clients write straight into their rows of
+            # it, peers' rows arrive there: no staging copy on either side
+            self._U_store = torch.zeros(self.K, ld, dtype=torch.float32, device=self.device)
+            r0 = int(np.sum(self.plan.rows_per_rank()[: runtime.rank]))
+            self.U_row = self._U_store[r0: r0 + self.Kloc, : self.Dpad]
+            self.U_col = self._U_store[:, : self.D]
+        else:
+            self._U_store = torch.zeros(self.Kloc, ld, dtype=torch.float32, device=self.device)
+            self.U_row = self._U_store[:, : self.Dpad]
+            self.U_col = self.U_row if G == 1 else torch.zeros(self.K, self.Dl, dtype=torch.float32,
+                                                                device=self.device)
         # Client chunks alternate over HIP streams so that one chunk's bandwidth-bound kernels (per-client BN,
         # elementwise) overlap another chunk's MFMA-bound convolutions: +3 % on the headline round with two
         # streams.  Multi-GPU runs keep one stream — there the gap is filled by the all-to-all pieces instead,
@@ -162,6 +172,7 @@ class ClientEngine:
         if self.mode in ("auto", "batched", "fused") and fused.supports(task.model):
             self.fused = fused.FusedFedSGD(task, self.names, self.offsets, self.numels, self.amp_dtype, self.device,
                                            conv_planes=self.conv_planes)
+            self.fused.template = swap_dropout(self.fused.template, self.drop_ctx)
         # several local steps: per-client weights -> grouped wide-network executor, if the model passes its
         # layout self-check (otherwise the torch.vmap path)
         self.grouped = None
@@ -171,6 +182,7 @@ class ClientEngine:
             if grouped.supports(task.model):
                 ge = grouped.GroupedLocalSGD(task, self.names, self.shapes, self.offsets[:-1], self.numels,
                                              self.amp_dtype, self.device)
+                ge.template = swap_dropout(ge.template, self.drop_ctx)
 
                 def ref(W, X, Y):
                     was = self.model.training
@@ -245,18 +257,36 @@ class ClientEngine:
             out[n] = v.reshape(*flat.shape[:-1], *s) if batched else v.reshape(s)
         return out
 
-    def _client_loss(self, params, x, y):
+    def _client_loss(self, params, x, y, uid=None):
+        if uid is not None:
+            self.drop_ctx.set(uid, "single")  # under vmap: a 0-dim batched tensor, one client per slice
+
         def m(inp):
             return functional_call(self.model, params, (inp,))
 
         with _autocast(self.device, self.amp_dtype):
             return self.task.loss(m, x, y)
 
-    def _grads(self, params, X, Y, per_client_params: bool):
+    def _grads(self, params, X, Y, per_client_params: bool, uids: Optional[torch.Tensor] = None):
         """Vectorised per-client (grads dict [Kc,…], losses [Kc])."""
-        fn = vmap(grad_and_value(self._client_loss), in_dims=(0 if per_client_params else None, 0, 0),
+        if uids is None:  # numerical self-checks: no dropout keys
+            fn = vmap(grad_and_value(self._client_loss), in_dims=(0 if per_client_params else None, 0, 0),
+                      randomness="different")
+            return fn(params, X, Y)
+        fn = vmap(grad_and_value(self._client_loss), in_dims=(0 if per_client_params else None, 0, 0, 0),
                   randomness="different")
-        return fn(params, X, Y)
+        return fn(params, X, Y, uids)
+
+    def _chunk_uids(self, srows: np.ndarray) -> torch.Tensor:
+        key = (b"u", srows.tobytes())
+        hit = self._row_vec_cache.get(key)
+        if hit is None:
+            hit = self._row_vec_cache[key] = torch.as_tensor(self._train_uids[srows], dtype=torch.int64,
+                                                             device=self.device)
+        return hit
+
+    def _drop_tag(self) -> int:
+        return self.round * self.nb + getattr(self, "_local_step", 0) + 1
 
     def _fetch_batch(self, srows: np.ndarray, flip: torch.Tensor):
         """One training batch per client of sampler rows ``srows`` -> X[Kc,B,…], Y[Kc,B]."""
@@ -345,7 +375,10 @@ class ClientEngine:
             store = self.train_store
             params = torch.zeros(Kc, 9, device=self.device) if aug else None  # transforms.N_PARAMS columns
 
+            uids_t = self._chunk_uids(srows)
+
             def body():
+                self.drop_ctx.set(uids_t, "major")
                 idx = self.sampler.gather_indices(dev_rows).reshape(-1)
                 X = store.x[idx].reshape(Kc, self.B, *store.x.shape[1:])
                 Y = store.y[idx].reshape(Kc, self.B)
@@ -370,6 +403,7 @@ class ClientEngine:
             # everything the graph reads by address must outlive it: keep the per-chunk tensors with the graph
             ent.update(graph=g, losses=losses, params=params, keep=(scale, flip, gscale, block, dev_rows))
         self.sampler.prepare(srows)
+        self.drop_ctx.set_tag(self._drop_tag())
         if aug:
             table = tf.draw(Kc, None, store_hw(self.train_store)[0], store_hw(self.train_store)[1],
                             uniforms=self._aug_uniforms(srows, tf))
@@ -388,6 +422,9 @@ class ClientEngine:
                 return losses
         gscale, flip, gclip = self._row_vectors(rows)
         X, Y = self._fetch_batch(srows, flip)
+        uids_t = self._chunk_uids(srows)
+        self.drop_ctx.set_tag(self._drop_tag())
+        self.drop_ctx.set(uids_t, "major")
         rows_t = self._chunk_consts(rows)[0]
         contiguous = int(rows[-1] - rows[0]) == len(rows) - 1
         plain = self.momentum == 0.0 and not self._any_clip
@@ -403,7 +440,7 @@ class ClientEngine:
                 return losses
             G = block[:, : self.D]
         else:
-            grads, losses = self._grads(self._params_from_flat(theta), X, Y, per_client_params=False)
+            grads, losses = self._grads(self._params_from_flat(theta), X, Y, per_client_params=False, uids=uids_t)
             G = torch.empty(len(rows), self.D, device=self.device)
             self._flatten_into(grads, G)
             del grads
@@ -441,10 +478,14 @@ class ClientEngine:
         for step in range(self.nb):
             self._local_step = step
             X, Y = self._fetch_batch(srows, flip)
+            uids_t = self._chunk_uids(srows)
+            self.drop_ctx.set_tag(self._drop_tag())
             if self.grouped is not None:
+                self.drop_ctx.set(uids_t, "inner")
                 losses = self.grouped.run(W, X, Y, G)
             else:
-                grads, losses = self._grads(self._params_from_flat(W, batched=True), X, Y, per_client_params=True)
+                grads, losses = self._grads(self._params_from_flat(W, batched=True), X, Y, per_client_params=True,
+                                            uids=uids_t)
                 self._flatten_into(grads, G)
                 del grads
             gs = gscale0
@@ -633,6 +674,7 @@ class ClientEngine:
         self._works = []
         self._send_keep = []
         self.ctx.stats["alltoall_bytes"] = 0
+        self.ctx.stats["allgather_bytes"] = 0
         row_off = np.concatenate([[0], np.cumsum(rows)])
         for q, (lo, hi) in enumerate(self._spans):  # rows nobody sends: zero (all ranks agree on which)
             if lo > 0:
@@ -654,6 +696,23 @@ class ClientEngine:
                 break
             self._next_piece += 1
             ops_ = []
+            if self.layout == "allgather":
+                # whole rows to every peer (contiguous slabs of the resident matrix on both sides)
+                if b > a:
+                    blk = self._U_store[row_off[me] + a: row_off[me] + b]
+                    for q in range(G):
+                        if q != me:
+                            ops_.append(dist.P2POp(dist.isend, blk, q))
+                for q in range(G):
+                    if q == me:
+                        continue
+                    qa, qb = self._piece_bounds(self._spans[q], j)
+                    if qb > qa:
+                        ops_.append(dist.P2POp(dist.irecv, self._U_store[row_off[q] + qa: row_off[q] + qb], q))
+                        self.ctx.stats["allgather_bytes"] += (qb - qa) * self._U_store.shape[1] * 4
+                if ops_:
+                    self._works.extend(dist.batch_isend_irecv(ops_))
+                continue
             if b > a:
                 # pack [rows, G*Dl] -> [G, rows, Dl]: one contiguous message per peer
                 send = self.U_row[a:b].view(b - a, G, Dl).transpose(0, 1).contiguous()
@@ -682,10 +741,13 @@ class ClientEngine:
         return self.U_col
 
     def gather_full(self) -> torch.Tensor:
-        """Explicit "all-gather the full update matrix" mode (BASELINE config #5):
-        every rank ends up with ``[K, D]``."""
+        """One-off all-gather of the update matrix (every rank ends up with ``[K, D]``).  The per-round
+        "allgather" layout (``update_layout="allgather"``, BASELINE config #5) does not come through here: it
+        sends finished row pieces while later chunks train, see ``_exchange_upto``."""
         if not self.ctx.distributed:
             return self.U_row[:, : self.D]
+        if self.layout == "allgather":
+            return self.U_col
         from blades_amd.parallel.communicator import all_gather_uneven_rows
 
         return all_gather_uneven_rows(self.U_row, self.plan.rows_per_rank())[:, : self.D]

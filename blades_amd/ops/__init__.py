@@ -189,3 +189,11 @@ def ce_topk(logits, labels, ks=(1,)):
     if logits.is_cuda and not _FORCE_REFERENCE:
         return _h().ce_topk(logits, labels, tuple(int(k) for k in ks))
     return ref.ce_topk(logits, labels, ks)
+
+
+def client_dropout_mult(uids, n, seed, tag, layer, p):
+    """Client-keyed dropout multipliers ``[Kc, n]`` (see reference.client_dropout_mult)."""
+    if uids.is_cuda and not _FORCE_REFERENCE and uids.dim() == 1 and torch.is_tensor(tag) and tag.is_cuda \
+            and not torch._C._functorch.is_batchedtensor(uids):
+        return _h().client_dropout_mult(uids, int(n), int(seed), tag, int(layer), float(p))
+    return ref.client_dropout_mult(uids, n, seed, tag, layer, p)

@@ -293,6 +293,22 @@ def philox_normal(n, seed, stream, offset, mean, std, device):
     return out
 
 
+_client_dropout = _sig("blades_client_dropout_mult", [_P, _P, c_int, c_long, _P, c_uint, c_ulonglong, c_float, _P])
+
+
+def client_dropout_mult(uids, n: int, seed: int, tag, layer: int, p: float):
+    if not (uids.is_cuda and uids.dtype == torch.int64 and uids.dim() == 1 and uids.is_contiguous()):
+        raise ValueError("client_dropout_mult: uids must be a contiguous CUDA int64 vector")
+    if not (tag.is_cuda and tag.dtype == torch.int64 and tag.numel() == 1):
+        raise ValueError("client_dropout_mult: tag must be a 1-element CUDA int64 tensor")
+    if not 0.0 <= p < 1.0:
+        raise ValueError("client_dropout_mult: need 0 <= p < 1")
+    out = torch.empty(uids.numel(), n, device=uids.device, dtype=torch.float32)
+    _client_dropout(_ptr(out), _ptr(uids), uids.numel(), n, _ptr(tag), (2 + 256 * layer) & 0xFFFFFFFF,
+                    seed & (2 ** 64 - 1), p, _stream())
+    return out
+
+
 def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite):
     K, Dl, ld = _chk_matrix(U)
     rows = rows.to(dtype=torch.int64, device="cpu").reshape(-1, 2)

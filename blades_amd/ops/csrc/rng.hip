@@ -53,7 +53,33 @@ __global__ __launch_bounds__(TPB) void normal_rows_kernel(float* U, long ld, lon
     p[c] = overwrite ? z : p[c] + z;
   }
 }
+// Client-keyed dropout multipliers: element e of client uid draws lane e & 3 of Philox counter
+// (e >> 2, uid, tag, c3) — a function of (seed, client, round/step tag, layer) only, so the masks a client sees do
+// not depend on which rank or chunk trains it.  `tag` is read from device memory: a captured HIP graph replays
+// the launch with the tag of the current round.
+__global__ __launch_bounds__(TPB) void client_dropout_kernel(float* __restrict__ out, const long* __restrict__ uids,
+                                                             long n, const long* __restrict__ tag, uint32_t c3,
+                                                             uint32_t k0, uint32_t k1, float p, float keep_scale) {
+  const long uid = uids[blockIdx.y];
+  const uint32_t t = (uint32_t)tag[0];
+  float* o = out + (size_t)blockIdx.y * n;
+  const long stride = (long)gridDim.x * TPB;
+  for (long e = (long)blockIdx.x * TPB + threadIdx.x; e < n; e += stride) {
+    const Philox4 r = philox4x32_10((uint32_t)(e >> 2), (uint32_t)uid, t, c3, k0, k1);
+    const int lane = (int)(e & 3);
+    const uint32_t x = lane == 0 ? r.x : lane == 1 ? r.y : lane == 2 ? r.z : r.w;
+    o[e] = u24(x) >= p ? keep_scale : 0.f;
+  }
+}
 }  // namespace
+
+BLADES_API void blades_client_dropout_mult(float* out, const long* uids, int Kc, long n, const long* tag, unsigned c3,
+                                           unsigned long long seed, float p, hipStream_t st) {
+  if (n <= 0 || Kc <= 0) return;
+  int g = cdiv(n, TPB); if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(client_dropout_kernel, dim3(g, Kc), dim3(TPB), 0, st, out, uids, n, tag, c3, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), p, 1.0f / (1.0f - p));
+}
 
 BLADES_API void blades_philox_uniform(float* out, long n, unsigned long long seed, unsigned stream,
                                       unsigned long long offset, hipStream_t st) {

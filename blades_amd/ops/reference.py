@@ -203,6 +203,27 @@ def philox_uniform(n: int, seed: int, stream: int, offset: int = 0, device="cpu"
     return ((x >> 8).to(torch.float32)) * (1.0 / 16777216.0)
 
 
+def client_dropout_mult(uids, n: int, seed: int, tag, layer: int, p: float):
+    """``[len(uids), n]`` dropout multipliers (0 or 1/(1-p)), keyed by client: element ``e`` of client ``uid``
+    uses lane ``e % 4`` of Philox counter ``(e//4, uid, tag, 2 + 256*layer)``.  ``tag`` (int or 1-element int64
+    tensor) identifies the round / local step.  ``uids`` may be a 0-dim tensor (one client, e.g. under vmap):
+    the result is then ``[n]``."""
+    single = uids.dim() == 0
+    u2 = uids.reshape(-1, 1)
+    e = torch.arange(n, dtype=torch.int64, device=uids.device).unsqueeze(0)
+    c0 = ((e >> 2) & _MASK) + torch.zeros_like(u2)
+    c1 = (u2 & _MASK) + torch.zeros_like(e)
+    t = tag.to(uids.device).reshape(1, 1) if torch.is_tensor(tag) else torch.tensor([[int(tag)]], device=uids.device)
+    c2 = (t & _MASK) + torch.zeros_like(c0)
+    c3 = torch.full_like(c0, (2 + 256 * int(layer)) & _MASK)
+    r = _philox4x32(c0, c1, c2, c3, seed & _MASK, (seed >> 32) & _MASK)
+    lane = e & 3
+    x = torch.where(lane == 0, r[0], torch.where(lane == 1, r[1], torch.where(lane == 2, r[2], r[3])))
+    u = ((x >> 8).to(torch.float32)) * (1.0 / 16777216.0)
+    m = (u >= p).to(torch.float32) * (1.0 / (1.0 - p))
+    return m[0] if single else m
+
+
 def philox_normal(n: int, seed: int, stream: int, offset: int = 0, mean=0.0, std=1.0, device="cpu"):
     """Box–Muller on Philox words: element ``e`` uses counter ``(e//2, stream, 1)``
     words (0,1) for even ``e`` (cos branch) and (2,3) for odd ``e`` (sin of the

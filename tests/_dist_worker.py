@@ -25,16 +25,10 @@ def main():
            .client(client_config={"lr": 0.5, "momentum": spec.get("cmom", 0.0), "num_batch_per_round": spec.get("nb", 1)})
            .adversary(num_malicious_clients=spec["f"], adversary_config=spec["adv"])
            .evaluation(evaluation_interval=spec["rounds"])
-           .engine(clients_per_chunk=3, amp_dtype=None, device="cpu"))
+           .engine(clients_per_chunk=3, amp_dtype=None, device="cpu", update_layout=spec.get("layout", "alltoall")))
     cfg.seed = 11
     algo = cfg.build()
-    # no dropout: torch's per-rank RNG is the one source of randomness that is not keyed by client
-    for m in [algo.engine.model, algo.server.get_global_model()] + (
-            [algo.engine.fused.template] if algo.engine.fused is not None else []) + (
-            [algo.engine.grouped.template] if getattr(algo.engine, "grouped", None) is not None else []):
-        for mod in m.modules():
-            if isinstance(mod, torch.nn.modules.dropout._DropoutNd):
-                mod.p = 0.0
+    # dropout stays on: the engine's masks are keyed by (seed, client, round, layer), not by the rank's RNG
     if spec.get("resume"):
         algo.load_checkpoint(spec["resume"])
     last = None
@@ -46,7 +40,8 @@ def main():
         algo.save_checkpoint(spec["ckpt"])
     if rt.is_main:
         torch.save({"theta": algo.server.theta[: algo.engine.D].clone(), "train_loss": last["train_loss"],
-                    "acc": last.get("acc_top_1"), "ce": last.get("ce_loss")}, out)
+                    "acc": last.get("acc_top_1"), "ce": last.get("ce_loss"),
+                    "comm_bytes": last.get("comm_bytes")}, out)
     shutdown_runtime()
 
 

@@ -110,3 +110,23 @@ def test_multi_rank_resume_equals_straight_run(tmp_path):
         got = run(world, dict(spec, rounds=2, resume=str(ck)), str(tmp_path / f"r{world}.pt"))
         torch.testing.assert_close(got["theta"], straight["theta"], rtol=1e-3, atol=1e-4)
         assert abs(got["train_loss"] - straight["train_loss"]) < 1e-4
+
+
+@pytest.mark.parametrize("agg", [{"type": "GeoMed"}, {"type": "Centeredclipping"}])
+def test_allgather_layout_equals_alltoall(tmp_path, agg):
+    """BASELINE config #5: "all-gather of the full update matrix".  Every rank receives [K, D] and aggregates
+    replicated; the result must be the one of the D-sharded all-to-all layout, at about G times the bytes."""
+    spec = {"K": 9, "f": 2, "agg": agg, "adv": {"type": "blades.adversaries.ALIEAdversary"}, "rounds": 3,
+            "root": str(tmp_path), "smom": 0.9}
+    ref = run(1, spec, str(tmp_path / "w1.pt"))
+    for world in (2, 3):
+        a2a = run(world, dict(spec, layout="alltoall"), str(tmp_path / f"a{world}.pt"))
+        ag = run(world, dict(spec, layout="allgather"), str(tmp_path / f"g{world}.pt"))
+        tol = 1e-3 if agg["type"] == "GeoMed" else 1e-4
+        torch.testing.assert_close(ag["theta"], ref["theta"], rtol=1e-3, atol=tol)
+        torch.testing.assert_close(ag["theta"], a2a["theta"], rtol=1e-3, atol=tol)
+        assert a2a["comm_bytes"]["alltoall"] > 0 and a2a["comm_bytes"]["allgather"] == 0
+        assert ag["comm_bytes"]["allgather"] > 0 and ag["comm_bytes"]["alltoall"] == 0
+        # rank 0 sends (G-1)/G of its rows' columns in the all-to-all, receives all columns of everybody else's
+        # training rows in the all-gather: roughly G times as much
+        assert ag["comm_bytes"]["allgather"] > 1.2 * a2a["comm_bytes"]["alltoall"]

@@ -142,3 +142,30 @@ def test_local_steps_do_not_depend_on_chunking(data_root, mode):
     torch.testing.assert_close(U2, U3, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(U1, U3, rtol=1e-5, atol=1e-6)
     assert float(U1.abs().sum(1).min()) > 0
+
+
+@pytest.mark.parametrize("model,ds", [("mlp", "fashionmnist"), ("cnn", "fashionmnist")])
+def test_client_keyed_dropout_is_active_and_path_independent(data_root, model, ds):
+    """Dropout stays on in the engine templates (ClientDropout, keyed by seed / client / round / layer): the fused,
+    vmap and — for several local steps — grouped executors see the same masks, and the masks matter."""
+    from blades_amd.engine.layers import ClientDropout
+
+    a = build(data_root, model, "fused", ds)
+    b = build(data_root, model, "vmap", ds)
+    drops = [m for m in a.engine.fused.template.modules() if isinstance(m, ClientDropout)]
+    assert drops and all(m.p > 0 for m in drops)
+    Ua, _ = one_round_updates(a)
+    Ub, _ = one_round_updates(b)
+    torch.testing.assert_close(Ua, Ub, rtol=1e-3, atol=2e-5)
+    c = build(data_root, model, "fused", ds)
+    c.engine.drop_ctx.enabled = False
+    Uc, _ = one_round_updates(c)
+    assert float((Ua - Uc).abs().max()) > 1e-4  # dropping really changed the gradients
+    # several local steps: grouped wide-network executor vs vmap, first round (later rounds amplify rounding)
+    g1 = build(data_root, model, "fused", ds, nb=2, lr=0.02)
+    g2 = build(data_root, model, "vmap", ds, nb=2, lr=0.02)
+    assert g1.engine.grouped is not None and g2.engine.grouped is None
+    U1, _ = one_round_updates(g1)
+    U2, _ = one_round_updates(g2)
+    rel = (U1 - U2).norm(dim=1) / U2.norm(dim=1)
+    assert float(rel.max()) < 5e-3, rel
