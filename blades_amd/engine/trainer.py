@@ -365,7 +365,8 @@ class ClientEngine:
             ent = self._chunk_graphs[key] = {"visits": 0, "graph": None}
         ent["visits"] += 1
         if ent["graph"] is None and ent["visits"] <= 2:
-            return None  # eager first: MIOpen kernel search, wgrad plans and scratch buffers settle outside capture
+            return None  # eager first: wgrad plan tables (host->device copies) and library kernel searches happen
+            # outside capture; the split-K scratch is a per-graph temporary (ops/_hip.py::_scratch)
         Kc = len(rows)
         if ent["graph"] is None:
             any_flip = self._any_flip
@@ -390,9 +391,18 @@ class ClientEngine:
 
             g = torch.cuda.CUDAGraph()
             try:
-                # every chunk graph gets a memory pool of its own: graphs sharing one pool produced sporadic
-                # non-finite rows in multi-chunk rounds; launch-bound rounds are small, so the memory is too
-                with torch.cuda.graph(g):
+                # Every chunk graph has a memory pool of its own (torch's default).  Round 1 saw sporadic
+                # non-finite rows when chunk graphs shared a pool.  Round-2 audit (tools/probes/poison_probe.py,
+                # multi_graph_probe.py; profiles/r2_graph_pool_audit.txt): with every kernel workspace / output
+                # pre-filled with NaN, eager, private-pool and shared-pool rounds are finite and bitwise equal
+                # (2 dtypes x 12 trials x 8 rounds), i.e. no kernel reads memory nothing wrote; what was left
+                # shared across graphs was the module-global split-K scratch slab, first allocated inside the
+                # first graph's capture (so owned by that graph's pool) and then written by every later graph.
+                # It is a per-graph temporary now.  Private pools stay: they cost nothing for these small rounds.
+                pool = None
+                if os.environ.get("BLADES_GRAPH_SHARED_POOL") == "1":  # diagnostics (tools/probes/poison_probe.py)
+                    pool = self.__dict__.setdefault("_graph_pool", torch.cuda.graph_pool_handle())
+                with torch.cuda.graph(g, pool=pool):
                     losses = body()
             except Exception as e:  # noqa: BLE001 — anything not capturable: stay eager for good
                 self._graph_failed = True

@@ -62,6 +62,31 @@ _pcbn_bwd = _sig("blades_pcbn_backward", [_P, _P, _P, _P, _P, _P, c_int, c_int, 
                                           c_int, _P, _P, _P, _P, _P, _P, c_int, _P], c_int)
 
 
+# Workspaces and outputs of the kernels come from here.  BLADES_POISON=1 fills them with NaN / 0xFF first: a kernel
+# that reads a byte nothing wrote then shows up as a non-finite result instead of depending on what the allocator
+# handed out (tools/probes/poison_probe.py).
+import os as _os
+
+_POISON = _os.environ.get("BLADES_POISON") == "1"
+
+
+def _poison(t: torch.Tensor) -> torch.Tensor:
+    if _POISON and t.numel():
+        if t.dtype.is_floating_point:
+            t.fill_(float("nan"))
+        else:
+            t.view(torch.uint8).fill_(0xFF)
+    return t
+
+
+def _empty(*a, **k):
+    return _poison(torch.empty(*a, **k))
+
+
+def _empty_like(*a, **k):
+    return _poison(torch.empty_like(*a, **k))
+
+
 def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -119,7 +144,7 @@ def _rows(rows: torch.Tensor, K: int, device) -> torch.Tensor:
 def weighted_col_sum(U, w):
     K, Dl, ld = _chk_matrix(U)
     w = _vec(w, K, U.device, name="w")
-    out = torch.empty(Dl, device=U.device, dtype=torch.float32)
+    out = _empty(Dl, device=U.device, dtype=torch.float32)
     _weighted_col_sum(_ptr(U), ld, K, Dl, _ptr(w), _ptr(out), _stream())
     return out
 
@@ -129,11 +154,11 @@ def _col_stats_call(U, mask, mode, a=1.0, z=0.0, sign=None, mal_rows=None):
     dev = U.device
     mask = _vec(mask, K, dev, name="mask")
     want_std, want_mm, forge = bool(mode & 1), bool(mode & 2), bool(mode & 4)
-    mean = torch.empty(Dl, device=dev)
-    std = torch.empty(Dl, device=dev) if want_std else None
-    mn = torch.empty(Dl, device=dev) if want_mm else None
-    mx = torch.empty(Dl, device=dev) if want_mm else None
-    vec = torch.empty(Dl, device=dev) if forge else None
+    mean = _empty(Dl, device=dev)
+    std = _empty(Dl, device=dev) if want_std else None
+    mn = _empty(Dl, device=dev) if want_mm else None
+    mx = _empty(Dl, device=dev) if want_mm else None
+    vec = _empty(Dl, device=dev) if forge else None
     sign = _vec(sign, Dl, dev, name="sign")
     n_mal = 0
     if forge and mal_rows is not None and mal_rows.numel():
@@ -197,7 +222,7 @@ def _order_stat_fill(mask, K: int, mode: int):
         pad = torch.where(torch.cumsum(dead, 0) % 2 == 1, inf, -inf)
     else:
         pad = inf.expand(N)
-    fill = torch.empty(N + 1, device=dev)
+    fill = _empty(N + 1, device=dev)
     fill[:N] = torch.where(dead, pad, torch.zeros((), device=dev))
     fill[N] = (K - dead[:K].sum()).to(torch.float32)
     return fill
@@ -209,7 +234,7 @@ def col_order_stat(U, mask, mode: int, b: int):
     if mode == 1 and mask is None and not 0 <= 2 * b < K:
         raise ValueError(f"trimmed mean needs 0 <= 2*b < K, got b={b}, K={K}")
     fill = None if mask is None else _order_stat_fill(mask, K, mode)
-    out = torch.empty(Dl, device=U.device)
+    out = _empty(Dl, device=U.device)
     rc = _col_order_stat(_ptr(U), ld, K, Dl, _ptr(fill), K, mode, b, _ptr(out), _stream())
     if rc == 1:
         raise ValueError(f"col_order_stat supports up to 2048 rows, got {K}")
@@ -223,10 +248,10 @@ def _row_reduce_call(U, kind, m=None, valid_cols=None, counts=False):
     dev = U.device
     m = _vec(m, Dl, dev, name="m")
     nch = _row_chunks(Dl)
-    part = torch.empty(K * nch, device=dev)
-    cpart = torch.empty(K * nch * 3, device=dev, dtype=torch.int32) if counts else None
-    out = torch.empty(K, device=dev)
-    cnt = torch.empty(K, 3, device=dev, dtype=torch.int64) if counts else None
+    part = _empty(K * nch, device=dev)
+    cpart = _empty(K * nch * 3, device=dev, dtype=torch.int32) if counts else None
+    out = _empty(K, device=dev)
+    cnt = _empty(K, 3, device=dev, dtype=torch.int64) if counts else None
     _row_reduce(_ptr(U), ld, K, Dl, Dl if valid_cols is None else int(valid_cols), _ptr(m), kind, _ptr(part),
                 _ptr(cpart), _ptr(out), _ptr(cnt), _stream())
     return out, cnt
@@ -249,8 +274,8 @@ def gram(U):
     tile, ntile, nsplit, cps = c_int(), c_int(), c_int(), c_long()
     _gram_plan(K, Dl, ctypes.byref(tile), ctypes.byref(ntile), ctypes.byref(nsplit), ctypes.byref(cps))
     Kp = tile.value * ntile.value
-    slabs = torch.empty(max(nsplit.value, 1) * Kp * Kp, device=U.device)
-    out = torch.empty(K, K, device=U.device)
+    slabs = _empty(max(nsplit.value, 1) * Kp * Kp, device=U.device)
+    out = _empty(K, K, device=U.device)
     _gram(_ptr(U), ld, K, Dl, _ptr(slabs), _ptr(out), _stream())
     return out
 
@@ -282,13 +307,13 @@ def client_sgd_step_(W, G, M, lr, momentum, first, gscale=None):
 
 
 def philox_uniform(n, seed, stream, offset, device):
-    out = torch.empty(n, device=device, dtype=torch.float32)
+    out = _empty(n, device=device, dtype=torch.float32)
     _philox_uniform(_ptr(out), n, seed & (2 ** 64 - 1), stream & 0xFFFFFFFF, offset, _stream())
     return out
 
 
 def philox_normal(n, seed, stream, offset, mean, std, device):
-    out = torch.empty(n, device=device, dtype=torch.float32)
+    out = _empty(n, device=device, dtype=torch.float32)
     _philox_normal(_ptr(out), n, seed & (2 ** 64 - 1), stream & 0xFFFFFFFF, offset, mean, std, _stream())
     return out
 
@@ -303,7 +328,7 @@ def client_dropout_mult(uids, n: int, seed: int, tag, layer: int, p: float):
         raise ValueError("client_dropout_mult: tag must be a 1-element CUDA int64 tensor")
     if not 0.0 <= p < 1.0:
         raise ValueError("client_dropout_mult: need 0 <= p < 1")
-    out = torch.empty(uids.numel(), n, device=uids.device, dtype=torch.float32)
+    out = _empty(uids.numel(), n, device=uids.device, dtype=torch.float32)
     _client_dropout(_ptr(out), _ptr(uids), uids.numel(), n, _ptr(tag), (2 + 256 * layer) & 0xFFFFFFFF,
                     seed & (2 ** 64 - 1), p, _stream())
     return out
@@ -334,7 +359,7 @@ def augment_batch(x, params, size, mean, std, validate: bool = True):
     if n and validate and (float((pc[:, 0] + pc[:, 2]).max()) > H or float((pc[:, 1] + pc[:, 2]).max()) > W
               or float(pc[:, :3].min()) < 0 or float(pc[:, 2].min()) < 1):
         raise ValueError("augment_batch: crop window out of bounds")
-    out = torch.empty(n, B, C, size, size, device=x.device, dtype=torch.float32)
+    out = _empty(n, B, C, size, size, device=x.device, dtype=torch.float32)
     m = (c_float * 4)(*(list(mean) + [0.0] * 4)[:4])
     s = (c_float * 4)(*(list(std) + [1.0] * 4)[:4])
     rc = _augment(_ptr(x), _ptr(params), _ptr(out), n, B, C, H, W, size, m, s, _stream())
@@ -376,11 +401,11 @@ def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask
     gamma = _vec(gamma, C, dev, name="gamma")
     beta = _vec(beta, C, dev, name="beta")
     nch = _pcbn_nchunk(P, C, x.element_size())
-    partial = torch.empty(Kc * nch * C * 2, device=dev)
-    stats = torch.empty(4, Kc, C, device=dev)
-    y = torch.empty_like(x)
+    partial = _empty(Kc * nch * C * 2, device=dev)
+    stats = _empty(4, Kc, C, device=dev)
+    y = _empty_like(x)
     # ReLU gate for the backward pass: 1 bit per element (8 channels of a pixel = 1 byte) instead of y itself
-    mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (relu and want_mask) else None
+    mask = _empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (relu and want_mask) else None
     rc = _pcbn_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), Kc, P, C, eps, int(relu), _ptr(partial),
                    _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(y), _ptr(mask), x.element_size(),
                    _stream())
@@ -417,10 +442,10 @@ def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block,
     if mean.numel() != Kc * C or invstd.numel() != Kc * C:
         raise ValueError("pcbn_backward: stats shape mismatch")
     nch = _pcbn_nchunk(P, C, x.element_size())
-    partial = torch.empty(Kc * nch * C * 2, device=dev)
-    k = torch.empty(3, Kc, C, device=dev)
-    dx = torch.empty_like(x)
-    gres = torch.empty_like(x) if want_gres else None
+    partial = _empty(Kc * nch * C * 2, device=dev)
+    k = _empty(3, Kc, C, device=dev)
+    dx = _empty_like(x)
+    gres = _empty_like(x) if want_gres else None
     rc = _pcbn_bwd(_ptr(x), _ptr(gy), _ptr(relu_mask), _ptr(gamma), _ptr(mean), _ptr(invstd), Kc, P, C, _ptr(coef),
                    _ptr(U_block), ld, off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(k[0]), _ptr(k[1]),
                    _ptr(k[2]), _ptr(dx), _ptr(gres), x.element_size(), _stream())
@@ -524,10 +549,14 @@ _scratch_buf = {}
 def _scratch(n: int, device) -> torch.Tensor:
     """Grow-only fp32 workspace per (device, stream): reuse is stream-ordered, so chunks that run on different
     streams must not share a slab."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a HIP-graph capture the slab is an ordinary temporary of that graph's memory pool: no graph ever
+        # reads or writes memory that a module-global handed over from another graph's pool
+        return _empty(int(n), device=device, dtype=torch.float32)
     key = (str(device), int(torch.cuda.current_stream().cuda_stream))
     buf = _scratch_buf.get(key)
     if buf is None or buf.numel() < n:
-        buf = torch.empty(int(n * 1.25) + 1024, device=device, dtype=torch.float32)
+        buf = _empty(int(n * 1.25) + 1024, device=device, dtype=torch.float32)
         _scratch_buf[key] = buf
     return buf
 
@@ -648,7 +677,7 @@ def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, 
         raise ValueError("conv_igemm: weight must be a contiguous CUDA fp32 [Co, Ci, kh, kw] tensor")
     if bias is not None:
         bias = _vec(bias.detach(), Co, inp.device, name="bias")
-    ws = torch.empty(_conv_igemm_ws(Co, Ci, kh, kw, mode, npl), dtype=torch.uint8, device=inp.device)
+    ws = _empty(_conv_igemm_ws(Co, Ci, kh, kw, mode, npl), dtype=torch.uint8, device=inp.device)
     rc = _conv_igemm(_ptr(inp), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad,
                      mode, npl, _stream())
     if rc != 0:
@@ -667,7 +696,7 @@ def conv_forward(x, weight, bias, stride: int, pad: int, npl: int):
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     if Ho < 1 or Wo < 1:
         raise ValueError("conv_forward: empty output")
-    y = torch.empty((N, Co, Ho, Wo), dtype=dt, device=x.device, memory_format=torch.channels_last)
+    y = _empty((N, Co, Ho, Wo), dtype=dt, device=x.device, memory_format=torch.channels_last)
     if Co == 1 or Ho * Wo == 1:
         y = y.as_strided(y.shape, (Ho * Wo * Co, 1, Wo * Co, Co))
     _conv_call(x, weight, bias, y, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 0, npl)
@@ -683,7 +712,7 @@ def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int):
     H, W = in_hw
     if Co2 != Co or Ho != (H + 2 * pad - kh) // stride + 1 or Wo != (W + 2 * pad - kw) // stride + 1:
         raise ValueError("conv_dgrad: gy does not match the convolution geometry")
-    dx = torch.empty((N, Ci, H, W), dtype=dt, device=gy.device, memory_format=torch.channels_last)
+    dx = _empty((N, Ci, H, W), dtype=dt, device=gy.device, memory_format=torch.channels_last)
     if Ci == 1 or H * W == 1:
         dx = dx.as_strided(dx.shape, (H * W * Ci, 1, W * Ci, Ci))
     _conv_call(gy, weight, None, dx, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 1, npl)
@@ -720,7 +749,7 @@ def ce_topk(logits, labels, ks):
     out = torch.zeros(1 + len(ks), dtype=torch.float64, device=lg.device)
     if N == 0:
         return out
-    part = torch.empty(((N + 255) // 256) * 9, dtype=torch.float64, device=lg.device)
+    part = _empty(((N + 255) // 256) * 9, dtype=torch.float64, device=lg.device)
     rc = _ce_topk(_ptr(lg), lg.stride(0), _ptr(y), N, C, ctypes.cast(karr, c_void_p), len(ks), _ptr(part), 0,
                   _ptr(out), _stream())
     if rc != 0:

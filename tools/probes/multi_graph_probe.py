@@ -12,7 +12,7 @@ for trial in range(6):
            .training(global_model="resnet", server_config={"aggregator": {"type": "Median"}, "optimizer": {"lr": 0.0}})
            .client(client_config={"lr": 1.0})
            .adversary(num_malicious_clients=2, adversary_config={"type": "blades.adversaries.ALIEAdversary"})
-           .evaluation(evaluation_interval=0).engine(clients_per_chunk=2))
+           .evaluation(evaluation_interval=0).engine(clients_per_chunk=2, amp_dtype=(sys.argv[1] if len(sys.argv) > 1 else "fp32")))
     cfg.seed = 5
     algo = cfg.build()
     bad_rounds = []
