@@ -222,7 +222,16 @@ class _PCLinearFn(torch.autograd.Function):
         dx = gy @ w if ctx.needs_input_grad[0] else None
         g3 = gy.reshape(Kc, -1, gy.shape[-1])  # [Kc, B*, out]
         x3 = x.reshape(Kc, -1, x.shape[-1])  # [Kc, B*, in]
-        sink.write(mod.weight, torch.bmm(g3.transpose(1, 2), x3))
+        if x.is_cuda and x.dtype == gy.dtype and x.dtype in (torch.float32, torch.bfloat16) \
+                and _os.environ.get("BLADES_DISABLE_HIP_WGRAD") != "1":
+            # grouped GEMM kernel: coef[c] * gy_c^T x_c lands in the update-matrix rows (no [Kc, out, in] temp)
+            off, _ = sink.offsets[id(mod.weight)]
+            acc = id(mod.weight) in sink._written
+            _hipmod().linear_wgrad_(x3.reshape(-1, x.shape[-1]), g3.reshape(-1, gy.shape[-1]), Kc, sink.block, off,
+                                    sink.scale, acc, sink.npl)
+            sink._written.add(id(mod.weight))
+        else:
+            sink.write(mod.weight, torch.bmm(g3.transpose(1, 2), x3))
         if mod.bias is not None:
             sink.write(mod.bias, g3.sum(dim=1, dtype=torch.float32))
         return dx, None, None
@@ -351,6 +360,12 @@ class _PCLayerNormFn(torch.autograd.Function):
     def forward(ctx, x, mod):
         if len(mod.normalized_shape) != 1:
             raise NotImplementedError("PCLayerNorm normalises the last dimension only")
+        ctx.hip = x.is_cuda and _hipmod().ln_supported(x)
+        if ctx.hip:  # one-wave-per-row kernel (ops/csrc/layernorm.hip); backward recomputes xhat from x
+            y, mean, rstd = _hipmod().ln_forward(x, mod.weight, mod.bias, mod.eps)
+            ctx.mod = mod
+            ctx.save_for_backward(x, mean, rstd)
+            return y
         xf = x.float()
         var, mean = torch.var_mean(xf, dim=-1, unbiased=False, keepdim=True)
         rstd = torch.rsqrt(var + mod.eps)
@@ -366,10 +381,24 @@ class _PCLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        xhat, rstd = ctx.saved_tensors
         mod = ctx.mod
         sink: GradSink = mod.sink
         Kc = sink.Kc
+        if ctx.hip:
+            x, mean, rstd = ctx.saved_tensors
+            offg = offb = -1
+            acc = False
+            if mod.weight is not None:
+                offg = sink.offsets[id(mod.weight)][0]
+                acc = id(mod.weight) in sink._written
+                sink._written.add(id(mod.weight))
+            if mod.bias is not None:
+                offb = sink.offsets[id(mod.bias)][0]
+                sink._written.add(id(mod.bias))
+            dx = _hipmod().ln_backward(x, gy.to(x.dtype), mod.weight, mean, rstd, Kc, sink.scale, sink.block, offg,
+                                       offb, acc)
+            return dx, None
+        xhat, rstd = ctx.saved_tensors
         xh, g = xhat.float(), gy.float()
         C = xh.shape[-1]
         if mod.weight is not None:

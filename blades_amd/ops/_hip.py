@@ -645,6 +645,93 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
 
 
 # ---------------------------------------------------------------------------
+# per-client LayerNorm (ops/csrc/layernorm.hip)
+_ln_nchunk = _sig("blades_ln_nchunk", [c_int], c_int)
+_ln_fwd = _sig("blades_ln_forward", [_P, _P, _P, c_long, c_int, c_float, _P, _P, _P, c_int, _P], c_int)
+_ln_bwd = _sig("blades_ln_backward", [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_long, c_long, c_long, c_int, _P,
+                                      _P, c_int, _P], c_int)
+
+
+def ln_supported(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype in _ACT_DTYPES and x.dim() >= 2 and x.shape[-1] <= 1024 and x.numel() > 0
+
+
+def ln_forward(x, gamma, beta, eps: float):
+    """LayerNorm over the last dimension.  Returns (y, mean [rows], rstd [rows])."""
+    if not ln_supported(x):
+        raise ValueError(f"ln_forward: unsupported input {x.dtype} {tuple(x.shape)}")
+    x = x.contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    gamma = _vec(gamma.detach(), C, x.device, name="gamma") if gamma is not None else None
+    beta = _vec(beta.detach(), C, x.device, name="beta") if beta is not None else None
+    y = _empty_like(x)
+    stats = _empty(2, rows, device=x.device, dtype=torch.float32)
+    rc = _ln_fwd(_ptr(x), _ptr(gamma), _ptr(beta), rows, C, eps, _ptr(y), _ptr(stats[0]), _ptr(stats[1]),
+                 x.element_size(), _stream())
+    if rc != 0:
+        raise ValueError("ln_forward: unsupported shape")
+    return y, stats[0], stats[1]
+
+
+def ln_backward(x, gy, gamma, mean, rstd, Kc: int, coef, U_block, off_gamma: int, off_beta: int, accumulate: bool):
+    """dx of LayerNorm; coef[c] * (dgamma_c, dbeta_c) go to U_block[c, off_gamma / off_beta : + C] (an offset < 0
+    skips that gradient).  Rows of ``x`` are client-major: rows / Kc per client."""
+    if not (ln_supported(x) and gy.dtype == x.dtype and gy.shape == x.shape):
+        raise ValueError("ln_backward: gy must match x")
+    x, gy = x.contiguous(), gy.contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if rows % Kc or mean.numel() != rows or rstd.numel() != rows:
+        raise ValueError("ln_backward: row count does not match")
+    R = rows // Kc
+    gamma = _vec(gamma.detach(), C, x.device, name="gamma") if gamma is not None else None
+    ld = 0
+    if U_block is not None:
+        K, Dl, ld = _chk_matrix(U_block)
+        if K != Kc or max(off_gamma, off_beta) + C > Dl:
+            raise ValueError("ln_backward: update-matrix block does not match")
+        coef = _vec(coef, Kc, x.device, name="coef")
+    partial = _empty(Kc * _ln_nchunk(R) * C * 2, device=x.device, dtype=torch.float32)
+    dx = _empty_like(x)
+    rc = _ln_bwd(_ptr(x), _ptr(gy), _ptr(gamma), _ptr(mean), _ptr(rstd), Kc, R, C, _ptr(coef), _ptr(U_block), ld,
+                 off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(dx), x.element_size(), _stream())
+    if rc != 0:
+        raise ValueError("ln_backward: unsupported shape")
+    return dx
+
+
+# ---------------------------------------------------------------------------
+# per-client Linear weight gradient (ops/csrc/linear_wgrad.hip)
+_linear_wgrad = _sig("blades_linear_wgrad", [_P, _P, _P, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             _P], c_int)
+
+
+def linear_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, npl: int = 3):
+    """U_block[c, off : off + Out*In] (+)= coef[c] * gy_c^T x_c for every client c; ``x`` is ``[Kc*R, In]``,
+    ``gy`` ``[Kc*R, Out]`` (bf16, or fp32 split in-kernel into ``npl`` bf16 planes)."""
+    if not (x.is_cuda and gy.is_cuda and x.dim() == 2 and gy.dim() == 2 and x.dtype == gy.dtype
+            and x.dtype in _ACT_DTYPES):
+        raise ValueError(f"linear_wgrad_: expected 2-D CUDA bf16/fp32 tensors of one dtype, got {x.dtype} "
+                         f"{tuple(x.shape)} / {gy.dtype} {tuple(gy.shape)}")
+    if x.shape[0] != gy.shape[0] or x.shape[0] % Kc:
+        raise ValueError("linear_wgrad_: row counts do not match the number of clients")
+    x = x if x.is_contiguous() and x.data_ptr() % 16 == 0 else x.contiguous().clone()
+    gy = gy if gy.is_contiguous() and gy.data_ptr() % 16 == 0 else gy.contiguous().clone()
+    R, In, Out = x.shape[0] // Kc, x.shape[1], gy.shape[1]
+    K, Dl, ld = _chk_matrix(U_block)
+    if K != Kc or off < 0 or off + Out * In > Dl:
+        raise ValueError("linear_wgrad_: update-matrix block does not match")
+    coef = _vec(coef, Kc, x.device, name="coef")
+    npl = 1 if x.dtype == torch.bfloat16 else (npl if npl in (2, 3) else 3)
+    rc = _linear_wgrad(_ptr(x), _ptr(gy), _ptr(U_block), ld, off, _ptr(coef), int(accumulate), Kc, R, In, Out, npl,
+                       _stream())
+    if rc != 0:
+        raise ValueError(f"linear_wgrad_: unsupported configuration (rc={rc})")
+    return True
+
+
+# ---------------------------------------------------------------------------
 # shared-weight convolution: forward and data gradient (ops/csrc/conv_igemm.hip)
 _conv_igemm_ws = _sig("blades_conv_igemm_ws", [c_int] * 6, c_long)
 _conv_igemm = _sig("blades_conv_igemm", [_P, _P, _P, _P, _P] + [c_int] * 13 + [_P], c_int)

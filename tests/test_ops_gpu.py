@@ -557,3 +557,84 @@ def test_kernels_are_bitwise_deterministic(dev):
         return Uw
 
     same(wgrad, "conv_wgrad_")
+
+
+def test_client_dropout_mult_matches_oracle(dev):
+    from blades_amd import ops
+    from blades_amd.ops import reference as ref
+
+    uids = torch.tensor([0, 5, 999, 123456], dtype=torch.int64, device=dev)
+    tag = torch.tensor([77], dtype=torch.int64, device=dev)
+    for n, layer, p in ((1000, 0, 0.2), (37, 3, 0.25), (4099, 1, 0.5)):
+        got = ops.client_dropout_mult(uids, n, 1234567, tag, layer, p)
+        exp = ref.client_dropout_mult(uids.cpu(), n, 1234567, 77, layer, p)
+        assert torch.equal(got.cpu(), exp)
+    # the tag is read on the device: changing it in place changes the masks (HIP-graph replays rely on that)
+    a = ops.client_dropout_mult(uids, 512, 1, tag, 0, 0.5)
+    tag.fill_(78)
+    b = ops.client_dropout_mult(uids, 512, 1, tag, 0, 0.5)
+    assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("Kc,R,In,Out", [(3, 64, 2304, 600), (5, 8, 600, 120), (4, 64, 120, 10), (2, 64, 784, 128),
+                                         (7, 33, 256, 10), (2, 512, 128, 128), (1, 5, 7, 3)])
+@pytest.mark.parametrize("npl", [3, 2, 1])
+def test_linear_wgrad_kernel(dev, Kc, R, In, Out, npl):
+    """Per-client Linear weight gradient (grouped GEMM into the update rows) against fp64 bmm."""
+    from blades_amd import ops
+
+    h = ops._h()
+    g = torch.Generator().manual_seed(Kc * 100 + In)
+    dt = torch.bfloat16 if npl == 1 else torch.float32
+    x = torch.randn(Kc * R, In, generator=g).to(dt).to(dev)
+    gy = torch.randn(Kc * R, Out, generator=g).to(dt).to(dev)
+    coef = torch.tensor([(-0.5) ** (i % 5) for i in range(Kc)], device=dev)
+    off = 3 if In % 4 else 8
+    U = torch.full((Kc, Out * In + 16), 7.0, device=dev)
+    h.linear_wgrad_(x, gy, Kc, U, off, coef, False, npl)
+    ref = torch.bmm(gy.double().reshape(Kc, R, Out).transpose(1, 2), x.double().reshape(Kc, R, In)) \
+        * coef.double().view(Kc, 1, 1)
+    got = U[:, off: off + Out * In].reshape(Kc, Out, In).double()
+    tol = {3: 1e-5, 2: 1e-4, 1: 1e-5}[npl]  # bf16 inputs are exact products, fp32 accumulation
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol * float(ref.abs().max()))
+    assert float((U[:, :off] - 7).abs().sum()) == 0 and float((U[:, off + Out * In:] - 7).abs().sum()) == 0
+    h.linear_wgrad_(x, gy, Kc, U, off, coef, True, npl)
+    got = U[:, off: off + Out * In].reshape(Kc, Out, In).double()
+    torch.testing.assert_close(got, 2 * ref, rtol=tol, atol=2 * tol * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("Kc,R,C", [(3, 512, 128), (2, 64, 256), (5, 7, 96), (1, 130, 1000), (4, 33, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_kernels(dev, Kc, R, C, dtype):
+    """Per-client LayerNorm forward / backward (affine gradients into the update rows) against fp64 autograd."""
+    from blades_amd import ops
+
+    h = ops._h()
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(Kc * R, C, generator=g) * 1.7 + 0.4).to(dtype).to(dev)
+    gy = torch.randn(Kc * R, C, generator=g).to(dtype).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = torch.randn(C, generator=g).to(dev)
+    y, mean, rstd = h.ln_forward(x, gamma, beta, 1e-5)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5)
+    f32 = dtype == torch.float32
+    torch.testing.assert_close(y.double(), yr.detach(), rtol=1e-5 if f32 else 2e-2, atol=1e-5 if f32 else 2e-2)
+    coef = torch.tensor([(-1.0) ** i * (i + 1) for i in range(Kc)], device=dev)
+    U = torch.full((Kc, 2 * C + 9), 7.0, device=dev)
+    dx = h.ln_backward(x, gy, gamma, mean, rstd, Kc, coef, U, 3, C + 5, False)
+    # per-client affine gradients: one backward per client
+    dg, db = torch.zeros(Kc, C, dtype=torch.float64), torch.zeros(Kc, C, dtype=torch.float64)
+    dxr = torch.zeros_like(xr)
+    for c in range(Kc):
+        sl = slice(c * R, (c + 1) * R)
+        a, b2, c2 = torch.autograd.grad(yr[sl], (xr, gr, br), gy[sl].double(), retain_graph=True)
+        dxr += a
+        dg[c], db[c] = b2.cpu() * float(coef[c]), c2.cpu() * float(coef[c])
+    torch.testing.assert_close(dx.double(), dxr, rtol=1e-4 if f32 else 3e-2, atol=1e-4 if f32 else 3e-2)
+    sc = max(1.0, float(dg.abs().max()))
+    tol = 1e-5 if f32 else 2e-2
+    torch.testing.assert_close(U[:, 3: 3 + C].double().cpu(), dg, rtol=tol * 10, atol=tol * sc)
+    torch.testing.assert_close(U[:, C + 5: 2 * C + 5].double().cpu(), db, rtol=tol * 10, atol=tol * sc)
+    assert float((U[:, :3] - 7).abs().sum()) == 0 and float((U[:, 2 * C + 5:] - 7).abs().sum()) == 0
