@@ -42,10 +42,25 @@ class GradSink:
         # operand planes of the hand-written convolution kernels (ops/csrc/conv_igemm.hip, conv_wgrad.hip):
         # 3 = fp32 activations, exact 3 x bf16 split (fp32 grade); 2 = fp32 activations, "bf16x3"; 1 = bf16
         self.npl = 3
+        # per-client weights (several local steps per round): [Kc, >= D] matrix whose row c holds client c's flat
+        # parameters; None = every client shares the model's own parameters (FedSGD)
+        self.W: Optional[torch.Tensor] = None
 
     def begin(self, block, scale, Kc, B):
         self.block, self.scale, self.Kc, self.B = block, scale, Kc, B
         self._written = set()
+
+    def param(self, p):
+        """The tensor a layer computes with: the shared parameter, or its per-client view ``[Kc, *p.shape]`` into
+        ``W`` (no copy: client stride = row stride of ``W``, contiguous inside a client)."""
+        if self.W is None or p is None:
+            return p
+        off, n = self.offsets[id(p)]
+        shape = (self.Kc,) + tuple(p.shape)
+        strides = [1] * len(p.shape)
+        for i in range(len(p.shape) - 2, -1, -1):
+            strides[i] = strides[i + 1] * p.shape[i + 1]
+        return self.W.as_strided(shape, (self.W.stride(0),) + tuple(strides), self.W.storage_offset() + off)
 
     def view(self, param) -> torch.Tensor:
         off, n = self.offsets[id(param)]
@@ -105,10 +120,14 @@ class _PCConvFn(torch.autograd.Function):
         ctx.mod = mod
         ctx.own = _own_conv(x, mod)
         if ctx.own:
-            # hand-written implicit-GEMM kernel; reads the fp32 master weights itself (split into bf16 planes)
-            ctx.save_for_backward(x, weight.detach())
-            return _hipmod().conv_forward(x, weight.detach(), mod.bias, int(mod.stride[0]), int(mod.padding[0]),
+            # hand-written implicit-GEMM kernel; reads the fp32 master weights itself (split into bf16 planes) —
+            # the shared ones, or each client's own set when the sink carries per-client weights
+            wk = mod.sink.param(weight).detach()
+            ctx.save_for_backward(x, wk)
+            return _hipmod().conv_forward(x, wk, mod.sink.param(mod.bias), int(mod.stride[0]), int(mod.padding[0]),
                                           mod.sink.npl)
+        if mod.sink.W is not None:
+            raise NotImplementedError("per-client weights need the hand-written convolution kernels")
         ctx.save_for_backward(x, w)
         return F.conv2d(x, w, b, mod.stride, mod.padding, mod.dilation, 1)
 
@@ -208,8 +227,17 @@ class PCConv2d(nn.Module):
 class _PCLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mod):
-        w = weight.to(x.dtype)
         ctx.mod = mod
+        if mod.sink.W is not None:
+            # per-client weights: one strided-batched library GEMM over the clients
+            Kc = mod.sink.Kc
+            w = mod.sink.param(weight).detach().to(x.dtype)  # [Kc, out, in]
+            ctx.save_for_backward(x, w)
+            y = torch.bmm(x.reshape(Kc, -1, x.shape[-1]), w.transpose(1, 2))
+            if mod.bias is not None:
+                y = y + mod.sink.param(mod.bias).detach().to(x.dtype).unsqueeze(1)
+            return y.reshape(*x.shape[:-1], w.shape[1])
+        w = weight.to(x.dtype)
         ctx.save_for_backward(x, w)
         return F.linear(x, w, mod.bias.to(x.dtype) if mod.bias is not None else None)
 
@@ -219,7 +247,10 @@ class _PCLinearFn(torch.autograd.Function):
         mod = ctx.mod
         sink: GradSink = mod.sink
         Kc = sink.Kc
-        dx = gy @ w if ctx.needs_input_grad[0] else None
+        if w.dim() == 3:
+            dx = torch.bmm(gy.reshape(Kc, -1, gy.shape[-1]), w).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        else:
+            dx = gy @ w if ctx.needs_input_grad[0] else None
         g3 = gy.reshape(Kc, -1, gy.shape[-1])  # [Kc, B*, out]
         x3 = x.reshape(Kc, -1, x.shape[-1])  # [Kc, B*, in]
         if x.is_cuda and x.dtype == gy.dtype and x.dtype in (torch.float32, torch.bfloat16) \
@@ -304,8 +335,10 @@ class _PCBatchNormFn(torch.autograd.Function):
         use_hip = x.is_cuda and _hipmod().pcbn_supported(x) and (res is None or _hipmod().pcbn_supported(res))
         if use_hip:
             # the kernel leaves the ReLU gate as a bitmask (1/16 of y's bytes) for the backward pass
-            y, mean, invstd, gate = _hipmod().pcbn_forward(x, res, mod.weight, mod.bias, Kc, mod.eps, relu,
-                                                           want_mask=True)
+            y, mean, invstd, gate = _hipmod().pcbn_forward(x, res, sink.param(mod.weight), sink.param(mod.bias),
+                                                           Kc, mod.eps, relu, want_mask=True)
+        elif sink.W is not None:
+            raise NotImplementedError("per-client weights need the hand-written batch-norm kernels")
         else:
             y, mean, invstd = _bn_forward_ref(x, res, mod.weight, mod.bias, Kc, mod.eps, relu)
             gate = y if relu else None
@@ -329,8 +362,8 @@ class _PCBatchNormFn(torch.autograd.Function):
                 acc = id(mod.weight) in sink._written
                 sink._written.add(id(mod.weight))
                 sink._written.add(id(mod.bias))
-            dx, gres = _hipmod().pcbn_backward(x, gy, y, mod.weight, mean, invstd, Kc, sink.scale, U, offg, offb,
-                                               acc, want_gres)
+            dx, gres = _hipmod().pcbn_backward(x, gy, y, sink.param(mod.weight), mean, invstd, Kc, sink.scale, U,
+                                               offg, offb, acc, want_gres)
         else:
             dx, gres, dgamma, dbeta = _bn_backward_ref(x, gy, y, mod.weight, mean, invstd, Kc, ctx.relu, want_gres)
             if mod.weight is not None:
@@ -360,6 +393,8 @@ class _PCLayerNormFn(torch.autograd.Function):
     def forward(ctx, x, mod):
         if len(mod.normalized_shape) != 1:
             raise NotImplementedError("PCLayerNorm normalises the last dimension only")
+        if mod.sink.W is not None:
+            raise NotImplementedError("per-client LayerNorm weights are not implemented (grouped / vmap path)")
         ctx.hip = x.is_cuda and _hipmod().ln_supported(x)
         if ctx.hip:  # one-wave-per-row kernel (ops/csrc/layernorm.hip); backward recomputes xhat from x
             y, mean, rstd = _hipmod().ln_forward(x, mod.weight, mod.bias, mod.eps)
@@ -608,6 +643,34 @@ class FusedFedSGD:
         losses.sum().backward()
         return losses.detach()
 
+
+    def run_per_client(self, W: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
+        """One local step with *per-client* weights (several batches per round, reference
+        fllib/clients/client.py:55-61): row c of ``W`` holds client c's flat parameters; the per-client gradients
+        go, unscaled, into ``G[Kc, D]``.  Same kernels as the shared-weight path — the convolution and batch-norm
+        kernels pick a client's weight set by image index, Linear layers run as one strided-batched GEMM."""
+        Kc, B = Y.shape
+        ones = torch.ones(Kc, device=W.device, dtype=torch.float32)
+        self.sink.begin(G, ones, Kc, B)
+        self.sink.W = W
+        try:
+            x = X.reshape(Kc * B, *X.shape[2:])
+            if self.amp_dtype is not None:
+                x = x.to(self.amp_dtype)
+            if x.dim() == 4 and x.is_cuda:
+                x = x.contiguous(memory_format=torch.channels_last)
+            self.template.train()
+            with torch.enable_grad():
+                logits = self.template(x)
+                lg = logits.float().reshape(Kc, B, -1)
+                losses = torch.vmap(lambda z, y: self.task.loss(_identity, z, y))(lg, Y)
+                losses.sum().backward()
+            missing = [k for k in self.sink.offsets if k not in self.sink._written]
+            if missing:
+                raise NotImplementedError(f"{len(missing)} parameters received no per-client gradient")
+            return losses.detach()
+        finally:
+            self.sink.W = None
 
     @torch.no_grad()
     def forward_only(self, X: torch.Tensor) -> torch.Tensor:

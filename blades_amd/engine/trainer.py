@@ -173,6 +173,12 @@ class ClientEngine:
             self.fused = fused.FusedFedSGD(task, self.names, self.offsets, self.numels, self.amp_dtype, self.device,
                                            conv_planes=self.conv_planes)
             self.fused.template = swap_dropout(self.fused.template, self.drop_ctx)
+        # several local steps (per-client weights), GPU: the fused executor itself, with the hand-written kernels
+        # picking each client's weight set (engine/fused.py::run_per_client); first NotImplementedError (a layer
+        # without a per-client kernel) drops to the grouped / vmap executors below for good
+        self.fused_pc = (self.fused is not None and self.nb > 1 and self.device.type == "cuda"
+                         and os.environ.get("BLADES_DISABLE_FUSED_PC") != "1")
+        self.fused_pc_error = None
         # several local steps: per-client weights -> grouped wide-network executor, if the model passes its
         # layout self-check (otherwise the torch.vmap path)
         self.grouped = None
@@ -490,7 +496,16 @@ class ClientEngine:
             X, Y = self._fetch_batch(srows, flip)
             uids_t = self._chunk_uids(srows)
             self.drop_ctx.set_tag(self._drop_tag())
-            if self.grouped is not None:
+            losses = None
+            if self.fused_pc:
+                try:
+                    self.drop_ctx.set(uids_t, "major")
+                    losses = self.fused.run_per_client(W, X, Y, G)
+                except NotImplementedError as e:
+                    self.fused_pc, self.fused_pc_error = False, str(e)
+            if losses is not None:
+                pass
+            elif self.grouped is not None:
                 self.drop_ctx.set(uids_t, "inner")
                 losses = self.grouped.run(W, X, Y, G)
             else:

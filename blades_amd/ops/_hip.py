@@ -57,9 +57,21 @@ _augment = _sig("blades_augment_batch", [_P, _P, _P, c_int, c_int, c_int, c_int,
 
 _pcbn_nchunk = _sig("blades_pcbn_nchunk", [c_int, c_int, c_int], c_int)
 _pcbn_fwd = _sig("blades_pcbn_forward", [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
-                                         c_int, _P], c_int)
+                                         c_int, c_int, _P], c_int)
 _pcbn_bwd = _sig("blades_pcbn_backward", [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_long, c_long, c_long,
-                                          c_int, _P, _P, _P, _P, _P, _P, c_int, _P], c_int)
+                                          c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P], c_int)
+
+
+def _affine(t, Kc: int, C: int, device, name: str):
+    """Affine vector of a per-client normalisation: [C] shared by all clients (stride 0) or [Kc, C] per client."""
+    if t is None:
+        return None, 0
+    t = t.detach()
+    if t.dim() == 2:
+        if tuple(t.shape) != (Kc, C):
+            raise ValueError(f"{name}: expected [{Kc}, {C}], got {tuple(t.shape)}")
+        return t.to(device=device, dtype=torch.float32).contiguous(), C
+    return _vec(t, C, device, name=name), 0
 
 
 # Workspaces and outputs of the kernels come from here.  BLADES_POISON=1 fills them with NaN / 0xFF first: a kernel
@@ -398,8 +410,10 @@ def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask
         if res.shape != x.shape:
             raise ValueError("residual shape mismatch")
     dev = x.device
-    gamma = _vec(gamma, C, dev, name="gamma")
-    beta = _vec(beta, C, dev, name="beta")
+    gamma, gstride = _affine(gamma, Kc, C, dev, "gamma")
+    beta, bstride = _affine(beta, Kc, C, dev, "beta")
+    if gamma is not None and beta is not None and gstride != bstride:
+        raise ValueError("pcbn_forward: gamma and beta must both be shared or both per client")
     nch = _pcbn_nchunk(P, C, x.element_size())
     partial = _empty(Kc * nch * C * 2, device=dev)
     stats = _empty(4, Kc, C, device=dev)
@@ -408,7 +422,7 @@ def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask
     mask = _empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (relu and want_mask) else None
     rc = _pcbn_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), Kc, P, C, eps, int(relu), _ptr(partial),
                    _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(y), _ptr(mask), x.element_size(),
-                   _stream())
+                   gstride, _stream())
     if rc != 0:
         raise ValueError("pcbn_forward: unsupported shape")
     if want_mask:
@@ -432,7 +446,7 @@ def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block,
     N, C, H, W = x.shape
     P = (N // Kc) * H * W
     dev = x.device
-    gamma = _vec(gamma, C, dev, name="gamma")
+    gamma, gstride = _affine(gamma, Kc, C, dev, "gamma")
     ld = 0
     if U_block is not None:
         K, Dl, ld = _chk_matrix(U_block)
@@ -448,7 +462,7 @@ def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block,
     gres = _empty_like(x) if want_gres else None
     rc = _pcbn_bwd(_ptr(x), _ptr(gy), _ptr(relu_mask), _ptr(gamma), _ptr(mean), _ptr(invstd), Kc, P, C, _ptr(coef),
                    _ptr(U_block), ld, off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(k[0]), _ptr(k[1]),
-                   _ptr(k[2]), _ptr(dx), _ptr(gres), x.element_size(), _stream())
+                   _ptr(k[2]), _ptr(dx), _ptr(gres), x.element_size(), gstride, _stream())
     if rc != 0:
         raise ValueError("pcbn_backward: unsupported shape")
     return dx, gres
@@ -733,8 +747,8 @@ def linear_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, npl
 
 # ---------------------------------------------------------------------------
 # shared-weight convolution: forward and data gradient (ops/csrc/conv_igemm.hip)
-_conv_igemm_ws = _sig("blades_conv_igemm_ws", [c_int] * 6, c_long)
-_conv_igemm = _sig("blades_conv_igemm", [_P, _P, _P, _P, _P] + [c_int] * 13 + [_P], c_int)
+_conv_igemm_ws = _sig("blades_conv_igemm_ws", [c_int] * 7, c_long)
+_conv_igemm = _sig("blades_conv_igemm", [_P, _P, _P, _P, _P] + [c_int] * 14 + [c_long, c_long, _P], c_int)
 
 #: operand planes per compute dtype: fp32 tensors are split exactly into 3 bf16 planes (6 MFMA products, fp32
 #: grade), "bf16x3" keeps 2 planes (3 products, ~2^-17), bf16 tensors run as they are
@@ -752,21 +766,36 @@ def _chk_nhwc(t: torch.Tensor, name: str, dtype):
 
 def conv_igemm_supported(x: torch.Tensor, weight: torch.Tensor, stride, pad, dilation, npl: int) -> bool:
     want = torch.bfloat16 if npl == 1 else torch.float32
-    kh, kw = weight.shape[2:]
+    kh, kw = weight.shape[-2:]
     return (x.is_cuda and x.dtype == want and x.dim() == 4 and weight.dtype == torch.float32
             and stride[0] == stride[1] and pad[0] == pad[1] and tuple(dilation) == (1, 1) and kh * kw <= 25
             and x.shape[3] + 2 * pad[1] >= kw and x.shape[3] <= 256)
 
 
 def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, mode, npl):
+    """``weight``: [Co, Ci, kh, kw] shared by every image, or [Kc, Co, Ci, kh, kw] — one weight set per client
+    (clients may be rows of a wider matrix: any stride along dim 0, contiguous inside a client)."""
     w = weight.detach()
-    if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (Co, Ci, kh, kw)):
-        raise ValueError("conv_igemm: weight must be a contiguous CUDA fp32 [Co, Ci, kh, kw] tensor")
+    nc, wstride, bstride = 1, 0, 0
+    if w.dim() == 5:
+        nc, wstride = int(w.shape[0]), int(w.stride(0))
+        ok = tuple(w.shape[1:]) == (Co, Ci, kh, kw) and w[0].is_contiguous() and N % nc == 0
+    else:
+        ok = tuple(w.shape) == (Co, Ci, kh, kw) and w.is_contiguous()
+    if not (ok and w.is_cuda and w.dtype == torch.float32):
+        raise ValueError("conv_igemm: weight must be a CUDA fp32 [Co, Ci, kh, kw] or [Kc, Co, Ci, kh, kw] tensor, "
+                         f"contiguous per client; got {tuple(w.shape)} strides {w.stride()}")
     if bias is not None:
-        bias = _vec(bias.detach(), Co, inp.device, name="bias")
-    ws = _empty(_conv_igemm_ws(Co, Ci, kh, kw, mode, npl), dtype=torch.uint8, device=inp.device)
+        b = bias.detach()
+        if nc > 1:
+            if not (b.dim() == 2 and tuple(b.shape) == (nc, Co) and b.stride(1) == 1 and b.dtype == torch.float32):
+                raise ValueError("conv_igemm: per-client bias must be fp32 [Kc, Co] with unit inner stride")
+            bstride, bias = int(b.stride(0)), b
+        else:
+            bias = _vec(b, Co, inp.device, name="bias")
+    ws = _empty(_conv_igemm_ws(Co, Ci, kh, kw, mode, npl, nc), dtype=torch.uint8, device=inp.device)
     rc = _conv_igemm(_ptr(inp), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad,
-                     mode, npl, _stream())
+                     mode, npl, nc, wstride, bstride, _stream())
     if rc != 0:
         raise ValueError(f"conv_igemm: unsupported configuration (rc={rc}): N={N} H={H} W={W} Ci={Ci} Co={Co} "
                          f"k={kh}x{kw} stride={stride} pad={pad} mode={mode} npl={npl}")
@@ -777,7 +806,7 @@ def conv_forward(x, weight, bias, stride: int, pad: int, npl: int):
     dt = torch.bfloat16 if npl == 1 else torch.float32
     _chk_nhwc(x, "x", dt)
     N, Ci, H, W = x.shape
-    Co, Ci2, kh, kw = weight.shape
+    Co, Ci2, kh, kw = weight.shape[-4:]
     if Ci2 != Ci:
         raise ValueError("conv_forward: channel mismatch")
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
@@ -795,7 +824,7 @@ def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int):
     dt = torch.bfloat16 if npl == 1 else torch.float32
     _chk_nhwc(gy, "gy", dt)
     N, Co, Ho, Wo = gy.shape
-    Co2, Ci, kh, kw = weight.shape
+    Co2, Ci, kh, kw = weight.shape[-4:]
     H, W = in_hw
     if Co2 != Co or Ho != (H + 2 * pad - kh) // stride + 1 or Wo != (W + 2 * pad - kw) // stride + 1:
         raise ValueError("conv_dgrad: gy does not match the convolution geometry")

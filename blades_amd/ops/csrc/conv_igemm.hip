@@ -68,6 +68,8 @@ struct IgemmParams {
   float inv_ws, inv_tr, inv_wi, inv_irwi;
   int tap_off[MAXTAPS];       // slot offset of tap t relative to a pixel's base slot
   int tap_w[MAXTAPS];         // index of tap t in the weight tensor
+  int n_clients, imgs_per_client;  // per-client weights (local steps > 1): image n uses weight set n / imgs_per_client
+  long wp_client_stride, bias_client_stride;  // elements between two clients' weight planes / biases
   int ablate;                 // diagnostics (BLADES_IGEMM_ABLATE): 1 no staging loads, 2 no commit, 4 no MFMAs
 };
 
@@ -99,6 +101,10 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   if (p.TI == 1) { img0 = mt / p.tiles_per_img; sy0 = (mt - img0 * p.tiles_per_img) * p.TR; }
   else { img0 = mt * p.TI; sy0 = 0; }
   const int iy_lo = sy0 * p.si + p.aymin;
+  // per-client weights: a tile never straddles two clients (plan() keeps TI a divisor of imgs_per_client)
+  const int client = p.n_clients > 1 ? img0 / p.imgs_per_client : 0;
+  const unsigned short* wp_c = p.wp + (size_t)client * p.wp_client_stride;
+  const float* bias_c = p.bias ? p.bias + (size_t)client * p.bias_client_stride : nullptr;
 
   const int a_plane = p.NS * 64, a_buf = NPL * a_plane;
   constexpr int b_plane = BN * 64;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   const int brow = tid >> 2, bkg = tid & 3;
   const size_t w_plane = (size_t)p.ntw * p.Cop * p.Cip;
   auto b_load = [&](int tw, int c0, int q) {
-    return *reinterpret_cast<const u32x4*>(p.wp + q * w_plane + ((size_t)tw * p.Cop + n0 + brow) * p.Cip + c0 + bkg * 8);
+    return *reinterpret_cast<const u32x4*>(wp_c + q * w_plane + ((size_t)tw * p.Cop + n0 + brow) * p.Cip + c0 + bkg * 8);
   };
   const int b_dst = brow * 64 + ((bkg * 16) ^ swz(brow));
   auto b_store = [&](u32x4 v, int q) { *reinterpret_cast<u32x4*>(B_lds + q * b_plane + b_dst) = v; };
@@ -301,9 +307,9 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
       const int co = n0 + cf * 16 + kg * 4;
       if (co >= p.Co) continue;
       f32x4 v = acc[pf][cf];
-      if (p.bias != nullptr) {
+      if (bias_c != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? p.bias[co + j] : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? bias_c[co + j] : 0.f;
       }
       if constexpr (SPLIT) {
         float* dst = reinterpret_cast<float*>(p.out) + out_pix[pf] * p.Co + co;
@@ -330,8 +336,10 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
 // wp[q][t][ci][co].  Rows / columns beyond the real channel counts are zero.
 __global__ __launch_bounds__(256) void conv_wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
                                                          int Co, int Ci, int taps, int rows, int rows_pad, int k,
-                                                         int k_pad, int transpose, int npl) {
+                                                         int k_pad, int transpose, int npl, long w_client_stride) {
   const size_t total = (size_t)taps * rows_pad * k_pad;
+  w += (size_t)blockIdx.y * w_client_stride;          // one weight set per client (grid.y), planes [client][npl][..]
+  wp += (size_t)blockIdx.y * npl * total;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int kk = (int)(i % k_pad);
     const size_t rr = i / k_pad;
@@ -380,7 +388,9 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
     if (force && atoi(force) != mf) continue;
     // candidates: TI whole images per tile (largest first), then row bands of one image (TR rows, fewest first
     // that fits the 160 KB of LDS: the staged receptive field grows with stride and kernel size)
-    const int ti_max = p.Hs * p.Ws * 2 <= BM ? BM / (p.Hs * p.Ws) : 1;
+    int ti_max = p.Hs * p.Ws * 2 <= BM ? BM / (p.Hs * p.Ws) : 1;
+    if (p.n_clients > 1)
+      while (ti_max > 1 && p.imgs_per_client % ti_max) --ti_max;
     int tr_max = BM / p.Ws;
     if (tr_max > p.Hs) tr_max = p.Hs;
     for (int ti = ti_max, tr = tr_max; ti >= 1 && tr >= 1;) {
@@ -406,7 +416,11 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
         if (best_mf == 0 || cost < best_cost) { best_mf = mf; best_cost = cost; best = q; }
         break;
       }
-      if (ti > 1) ti >>= 1; else --tr;
+      if (ti > 1) {
+        ti >>= 1;
+        if (p.n_clients > 1)
+          while (ti > 1 && p.imgs_per_client % ti) --ti;
+      } else --tr;
     }
   }
   if (best_mf) p = best;
@@ -453,19 +467,24 @@ int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t 
 }  // namespace
 
 // bytes of weight-plane workspace a call needs
-BLADES_API long blades_conv_igemm_ws(int Co, int Ci, int kh, int kw, int mode, int npl) {
+BLADES_API long blades_conv_igemm_ws(int Co, int Ci, int kh, int kw, int mode, int npl, int n_clients) {
   const int rows = mode == 0 ? Co : Ci, k = mode == 0 ? Ci : Co;
-  return (long)npl * kh * kw * round_up(rows, BN) * round_up(k, KC) * 2;
+  return (long)(n_clients < 1 ? 1 : n_clients) * npl * kh * kw * round_up(rows, BN) * round_up(k, KC) * 2;
 }
 
 // mode 0: forward    in = x  [N,H,W,Ci]   -> out = y  [N,Ho,Wo,Co]   (bias optional)
 // mode 1: data grad  in = gy [N,Ho,Wo,Co] -> out = dx [N,H,W,Ci]
 // w: [Co][Ci][kh][kw] fp32 contiguous.  npl 3 / 2: fp32 tensors; npl 1: bf16 tensors.
+// n_clients > 1: per-client weights — image n uses the weight set n / (N / n_clients), found at
+// w + client * w_client_stride (bias + client * bias_client_stride); the FedSGD fast path passes n_clients = 1.
 // returns 0 ok; nonzero = unsupported (caller falls back)
 BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
                                  int W, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad, int mode,
-                                 int npl, hipStream_t st) {
+                                 int npl, int n_clients, long w_client_stride, long bias_client_stride,
+                                 hipStream_t st) {
   if (npl < 1 || npl > 3 || kh * kw > MAXTAPS || stride < 1 || N <= 0) return 1;
+  if (n_clients < 1) n_clients = 1;
+  if (N % n_clients || n_clients > 65535) return 5;
   if (Ho != (H + 2 * pad - kh) / stride + 1 || Wo != (W + 2 * pad - kw) / stride + 1) return 2;
   const int taps = kh * kw;
   const int rows = mode == 0 ? Co : Ci, k = mode == 0 ? Ci : Co;
@@ -474,13 +493,15 @@ BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bi
     const size_t total = (size_t)taps * rows_pad * k_pad;
     int gx = cdiv((long)total, 256);
     if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(conv_wprep_kernel, dim3(gx), dim3(256), 0, st, w, (unsigned short*)ws, Co, Ci, taps, rows,
-                       rows_pad, k, k_pad, mode, npl);
+    hipLaunchKernelGGL(conv_wprep_kernel, dim3(gx, n_clients), dim3(256), 0, st, w, (unsigned short*)ws, Co, Ci, taps,
+                       rows, rows_pad, k, k_pad, mode, npl, w_client_stride);
   }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.in = in; p.wp = (const unsigned short*)ws; p.out = out; p.bias = mode == 0 ? bias : nullptr;
   p.N = N; p.ntw = taps; p.Cop = rows_pad; p.Cip = k_pad;
+  p.n_clients = n_clients; p.imgs_per_client = N / n_clients;
+  p.wp_client_stride = (long)npl * taps * rows_pad * k_pad; p.bias_client_stride = bias_client_stride;
   int ay[MAXTAPS], ax[MAXTAPS];
   if (mode == 0) {
     p.Hi = H; p.Wi = W; p.Ci = Ci; p.Hout = Ho; p.Wout = Wo; p.Co = Co;

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(TPB) void pcbn_reduce_kernel(const T* __restrict__ 
 // forward finalize: one thread per (client, channel)
 __global__ __launch_bounds__(TPB) void pcbn_fwd_finalize_kernel(const float* __restrict__ partial, int Kc, int C, int nchunk,
                                                                 int P, float eps, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, float* __restrict__ mean,
+                                                                const float* __restrict__ beta, int gstride,
+                                                                float* __restrict__ mean,
                                                                 float* __restrict__ invstd, float* __restrict__ scale,
                                                                 float* __restrict__ shift) {
   const int i = blockIdx.x * TPB + threadIdx.x;
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_finalize_kernel(const float* __r
   double var = ss / P - m * m;
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
-  const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+  // gstride = 0: one affine pair shared by all clients (FedSGD); = C: per-client pairs [Kc][C] (local steps > 1)
+  const float g = gamma ? gamma[(size_t)c * gstride + ch] : 1.f, b = beta ? beta[(size_t)c * gstride + ch] : 0.f;
   mean[i] = (float)m; invstd[i] = is;
   scale[i] = g * is; shift[i] = b - (float)m * g * is;
 }
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const T* __restrict
 
 // backward finalize: dgamma/dbeta -> update-matrix rows (scaled), coefficient tables for apply
 __global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_kernel(const float* __restrict__ partial, int Kc, int C, int nchunk,
-                                                                int P, const float* __restrict__ gamma,
+                                                                int P, const float* __restrict__ gamma, int gstride,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ coef,  // [Kc] sink scale
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_kernel(const float* __r
     const float* q = partial + ((size_t)(c * nchunk + k) * C + ch) * 2;
     sg += (double)q[0]; sgx += (double)q[1];
   }
-  const float g = gamma ? gamma[ch] : 1.f;
+  const float g = gamma ? gamma[(size_t)c * gstride + ch] : 1.f;
   if (U != nullptr) {
     float* row = U + (size_t)c * ld;
     const float s = coef[c];
@@ -250,14 +252,14 @@ inline int chunk_pixels(int C, int esize = 2) {
 }
 
 template <typename T>
-int pcbn_forward_t(const void* x, const void* res, const float* gamma, const float* beta, int Kc, int P, int C, float eps,
+int pcbn_forward_t(const void* x, const void* res, const float* gamma, const float* beta, int gstride, int Kc, int P, int C, float eps,
                    int relu, float* partial, float* mean, float* invstd, float* scale, float* shift, void* y,
                    void* relu_mask, hipStream_t st) {
   const int ppc = chunk_pixels(C, sizeof(T)), nch = cdiv(P, ppc);
   hipLaunchKernelGGL((pcbn_reduce_kernel<0, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
                      (const T*)nullptr, nullptr, nullptr, nullptr, P, C, ppc, nch, partial);
   hipLaunchKernelGGL(pcbn_fwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
-                     eps, gamma, beta, mean, invstd, scale, shift);
+                     eps, gamma, beta, gstride, mean, invstd, scale, shift);
   int gx = cdiv((long)P * (C / 8), TPB);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL((pcbn_fwd_apply_kernel<T>), dim3(gx, Kc), dim3(TPB), 0, st, (const T*)x, (const T*)res, scale,
@@ -266,7 +268,7 @@ int pcbn_forward_t(const void* x, const void* res, const float* gamma, const flo
 }
 
 template <typename T>
-int pcbn_backward_t(const void* x, const void* gy, const void* relu_mask, const float* gamma, const float* mean,
+int pcbn_backward_t(const void* x, const void* gy, const void* relu_mask, const float* gamma, int gstride, const float* mean,
                     const float* invstd, int Kc, int P, int C, const float* coef, float* U, long ld, long off_gamma,
                     long off_beta, int accumulate, float* partial, float* k_scale, float* k_b, float* k_c, void* dx,
                     void* gres, hipStream_t st) {
@@ -274,7 +276,7 @@ int pcbn_backward_t(const void* x, const void* gy, const void* relu_mask, const 
   hipLaunchKernelGGL((pcbn_reduce_kernel<1, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
                      (const T*)gy, (const unsigned char*)relu_mask, mean, invstd, P, C, ppc, nch, partial);
   hipLaunchKernelGGL(pcbn_bwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
-                     gamma, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c);
+                     gamma, gstride, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c);
   int gx = cdiv((long)P * (C / 8), TPB);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL((pcbn_bwd_apply_kernel<T>), dim3(gx, Kc), dim3(TPB), 0, st, (const T*)x, (const T*)gy,
@@ -290,13 +292,14 @@ BLADES_API int blades_pcbn_nchunk(int P, int C, int esize) { return cdiv(P, chun
 // workspace `partial`: Kc * nchunk * C * 2 floats.
 BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* gamma, const float* beta, int Kc,
                                    int P, int C, float eps, int relu, float* partial, float* mean, float* invstd,
-                                   float* scale, float* shift, void* y, void* relu_mask, int esize, hipStream_t st) {
+                                   float* scale, float* shift, void* y, void* relu_mask, int esize, int gstride,
+                                   hipStream_t st) {
   if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
   if (esize == 4)
-    return pcbn_forward_t<float>(x, res, gamma, beta, Kc, P, C, eps, relu, partial, mean, invstd, scale, shift, y,
+    return pcbn_forward_t<float>(x, res, gamma, beta, gstride, Kc, P, C, eps, relu, partial, mean, invstd, scale, shift, y,
                                  relu_mask, st);
   if (esize == 2)
-    return pcbn_forward_t<unsigned short>(x, res, gamma, beta, Kc, P, C, eps, relu, partial, mean, invstd, scale,
+    return pcbn_forward_t<unsigned short>(x, res, gamma, beta, gstride, Kc, P, C, eps, relu, partial, mean, invstd, scale,
                                           shift, y, relu_mask, st);
   return 2;
 }
@@ -307,13 +310,13 @@ BLADES_API int blades_pcbn_backward(const void* x, const void* gy, const void* r
                                     const float* mean, const float* invstd, int Kc, int P, int C, const float* coef,
                                     float* U, long ld, long off_gamma, long off_beta, int accumulate, float* partial,
                                     float* k_scale, float* k_b, float* k_c, void* dx, void* gres, int esize,
-                                    hipStream_t st) {
+                                    int gstride, hipStream_t st) {
   if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
   if (esize == 4)
-    return pcbn_backward_t<float>(x, gy, relu_mask, gamma, mean, invstd, Kc, P, C, coef, U, ld, off_gamma, off_beta,
+    return pcbn_backward_t<float>(x, gy, relu_mask, gamma, gstride, mean, invstd, Kc, P, C, coef, U, ld, off_gamma, off_beta,
                                   accumulate, partial, k_scale, k_b, k_c, dx, gres, st);
   if (esize == 2)
-    return pcbn_backward_t<unsigned short>(x, gy, relu_mask, gamma, mean, invstd, Kc, P, C, coef, U, ld, off_gamma,
+    return pcbn_backward_t<unsigned short>(x, gy, relu_mask, gamma, gstride, mean, invstd, Kc, P, C, coef, U, ld, off_gamma,
                                            off_beta, accumulate, partial, k_scale, k_b, k_c, dx, gres, st);
   return 2;
 }
