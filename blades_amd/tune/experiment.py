@@ -69,12 +69,49 @@ def make_trials(name: str, spec: Dict[str, Any]) -> List[Dict[str, Any]]:
     return trials
 
 
-def _gpus_of(cfg: Dict[str, Any]) -> int:
-    """How many whole GPUs a trial occupies.  The Ray-era fractional requests
-    (``num_gpus_for_driver: 0.25`` = "4 trials per GPU") map to one GPU; an explicit
-    ``num_gpus`` / ``world_size`` key asks for a multi-GPU (RCCL) trial."""
+def _gpus_of(cfg: Dict[str, Any]) -> float:
+    """GPU share of a trial.  An explicit ``num_gpus`` / ``world_size`` key asks for that many whole GPUs (an RCCL
+    trial, one rank per GPU).  Otherwise the reference's fractional requests are honoured the way Tune packs
+    them (``num_gpus_for_driver: 0.25`` with one worker at 0.25 = half a GPU = two trials per device,
+    blades/tuned_examples/fedavg_60_mnist.yaml): the reference-sized rounds take 1-15 ms and are launch-bound, so
+    several trial processes share a device without slowing each other much.  No GPU request = one whole GPU."""
     n = cfg.get("world_size") or cfg.get("num_gpus") or 0
-    return max(1, int(n)) if n else 1
+    if n:
+        return float(max(1, int(n)))
+    frac = float(cfg.get("num_gpus_for_driver") or 0) + float(cfg.get("num_remote_workers") or 0) * float(
+        cfg.get("num_gpus_per_worker") or 0)
+    if frac <= 0 or frac >= 1:
+        return 1.0
+    return max(frac, 1.0 / 16)  # at most 16 processes per device
+
+
+class GpuSlots:
+    """Fractional GPU bookkeeping of the trial scheduler: whole-GPU requests take free devices, fractional ones
+    are packed onto the device with the least room that still fits (so whole devices stay free for big trials)."""
+
+    def __init__(self, num_gpus: int):
+        self.free = [1.0] * max(num_gpus, 1)
+
+    def acquire(self, need: float):
+        eps = 1e-9
+        if need >= 1:
+            n = int(round(need))
+            idle = [g for g, f in enumerate(self.free) if f >= 1 - eps]
+            if len(idle) < n:
+                return None
+            for g in idle[:n]:
+                self.free[g] = 0.0
+            return [(g, 1.0) for g in idle[:n]]
+        fits = [g for g, f in enumerate(self.free) if f + eps >= need]
+        if not fits:
+            return None
+        g = min(fits, key=lambda k: self.free[k])
+        self.free[g] -= need
+        return [(g, need)]
+
+    def release(self, token):
+        for g, share in token:
+            self.free[g] = min(1.0, self.free[g] + share)
 
 
 def latest_checkpoint(trial_dir: str) -> Optional[str]:
@@ -165,7 +202,8 @@ def run_trial(trial: Dict[str, Any], resume: bool = False, verbose: int = 1) -> 
 class TrialScheduler:
     """Runs trials as subprocesses pinned to GPUs (see module docstring)."""
 
-    def __init__(self, num_gpus: Optional[int] = None, max_concurrent: Optional[int] = None):
+    def __init__(self, num_gpus: Optional[int] = None, max_concurrent: Optional[int] = None, popen=subprocess.Popen):
+        self._popen = popen
         if num_gpus is None:
             try:
                 import torch
@@ -177,18 +215,21 @@ class TrialScheduler:
         self.max_concurrent = max_concurrent
 
     def run(self, trials: List[Dict[str, Any]], resume: bool = False, verbose: int = 1) -> List[int]:
-        free = list(range(max(self.num_gpus, 1)))
-        running = []  # (proc, gpus, trial, specfile)
+        slots = GpuSlots(self.num_gpus)
+        running = []  # (proc, slot token, trial, specfile)
         pending = list(trials)
         rcs = []
         port = 23456
+        self.max_in_flight = 0
         while pending or running:
             while pending and (self.max_concurrent is None or len(running) < self.max_concurrent):
-                need = pending[0]["gpus_per_trial"] if self.num_gpus else 1
-                if len(free) < need:
+                need = float(pending[0]["gpus_per_trial"]) if self.num_gpus else 1.0
+                token = slots.acquire(need)
+                if token is None:
                     break
                 trial = pending.pop(0)
-                gpus = [free.pop(0) for _ in range(need)]
+                gpus = [g for g, _ in token]
+                need = len(gpus)
                 spec = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
                 json.dump({"trial": trial, "resume": resume, "verbose": verbose}, spec)
                 spec.close()
@@ -202,7 +243,8 @@ class TrialScheduler:
                            "blades_amd.tune.trial_worker", spec.name]
                 else:
                     cmd = [sys.executable, "-m", "blades_amd.tune.trial_worker", spec.name]
-                running.append((subprocess.Popen(cmd, env=env), gpus, trial, spec.name))
+                running.append((self._popen(cmd, env=env), token, trial, spec.name))
+                self.max_in_flight = max(self.max_in_flight, len(running))
             still = []
             for proc, gpus, trial, specfile in running:
                 rc = proc.poll()
@@ -210,7 +252,7 @@ class TrialScheduler:
                     still.append((proc, gpus, trial, specfile))
                 else:
                     rcs.append(rc)
-                    free.extend(gpus)
+                    slots.release(gpus)
                     os.unlink(specfile)
                     if rc != 0:
                         print(f"[tune] trial {trial['dir_name']} failed with exit code {rc}", file=sys.stderr)

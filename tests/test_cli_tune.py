@@ -136,3 +136,34 @@ def test_early_stopping_schedulers(tmp_path):
     assert asha.should_stop(str(exp), "mine", {"training_iteration": 40, "acc_top_1": 0.99})      # budget reached
     with pytest.raises(ValueError):
         create_scheduler("pbt")
+
+
+def test_fractional_gpu_trials_are_packed():
+    """``num_gpus_for_driver: 0.25`` (reference YAMLs) = four trial processes per device; whole-GPU and multi-GPU
+    requests keep whole devices."""
+    from blades_amd.tune.experiment import GpuSlots, TrialScheduler, _gpus_of
+
+    assert _gpus_of({"num_gpus_for_driver": 0.25}) == 0.25
+    assert _gpus_of({"num_gpus_for_driver": 0.25, "num_remote_workers": 1, "num_gpus_per_worker": 0.25}) == 0.5
+    assert _gpus_of({}) == 1.0 and _gpus_of({"num_gpus_for_driver": 1}) == 1.0 and _gpus_of({"world_size": 4}) == 4.0
+    s = GpuSlots(2)
+    a = [s.acquire(0.25) for _ in range(4)]
+    assert all(t is not None and t[0][0] == a[0][0][0] for t in a)  # packed onto one device
+    whole = s.acquire(1.0)
+    assert whole is not None and whole[0][0] != a[0][0][0]
+    assert s.acquire(0.25) is None and s.acquire(1.0) is None
+    s.release(a[0])
+    assert s.acquire(0.25) is not None
+
+    class FakeProc:  # finishes on its third poll
+        def __init__(self, cmd, env=None):
+            self.n, self.env = 0, env
+
+        def poll(self):
+            self.n += 1
+            return 0 if self.n >= 3 else None
+
+    trials = [{"gpus_per_trial": 0.25, "dir_name": f"t{i}"} for i in range(6)]
+    sched = TrialScheduler(num_gpus=1, popen=FakeProc)
+    assert sched.run(trials) == [0] * 6
+    assert sched.max_in_flight == 4  # four quarter-GPU trials share the one device
