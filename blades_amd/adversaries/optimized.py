@@ -162,11 +162,12 @@ class AttackclippedclusteringAdversary(Adversary):
         mm = (mean * mean).sum().unsqueeze(0)
         if ctx.distributed:
             ctx.all_reduce(dots), ctx.all_reduce(mm)
-        dots = dots[bidx].double().cpu().numpy()
-        mean_norm = float(mm.sqrt())
-        norms = G.diagonal().clamp_min(0).sqrt().double().cpu().numpy()
+        # two device->host copies in all: the scalars below and the K x K distance matrix for the host clustering
+        num = int(bidx.numel())
+        packed = torch.cat([dots[bidx].double(), G.diagonal().clamp_min(0).sqrt().double(), mm.sqrt().double()])
+        packed = packed.cpu().numpy()
+        dots, norms, mean_norm = packed[:num], packed[num: 2 * num], float(packed[2 * num])
         dis = cosine_distance_from_gram(G)
-        num = len(norms)
         labels = host.agglomerative2(dis, "single")
         off = dis + np.eye(num) * 10.0
         dis_cross = float(off.min()) if num > 1 else 0.0
@@ -181,8 +182,9 @@ class AttackclippedclusteringAdversary(Adversary):
         alpha, beta = 0.0, 1.0 / max(norms[far], 1e-16)
         x_far = U[bidx[far]].clone()
         mrows = algorithm.malicious_rows
-        rows = mrows[torch.argsort(algorithm.malicious_row_clients.to(mrows.device))].tolist()
-        for r in rows:
+        rows = mrows[torch.argsort(algorithm.malicious_row_clients.to(mrows.device))]
+        coef = []
+        for _ in range(int(rows.numel())):  # scalar recurrence on the host, no device work
             if theta + theta_cross >= math.pi:
                 alpha, beta = -10.0, 0.0
             else:
@@ -191,7 +193,13 @@ class AttackclippedclusteringAdversary(Adversary):
                 cb = math.cos(theta_cross - 1e-4) + math.sin(theta_cross - 1e-4) / t
                 alpha, beta = 10 * (ca / mean_norm + cb * alpha), 10 * cb * beta
                 theta = theta + theta_cross - 1e-4
-            U[r] = alpha * mean + beta * x_far
+            coef.append((alpha, beta))
+        if coef:
+            ab = torch.tensor(coef, dtype=U.dtype, device=U.device)
+            basis = torch.stack([mean, x_far])  # [2, D]
+            step = max(1, (64 << 20) // max(U.shape[1], 1))  # rows per write: <= 256 MB of temporaries
+            for i in range(0, len(coef), step):
+                U[rows[i: i + step]] = ab[i: i + step] @ basis
 
 
 def find_orthogonal_unit_vector(v: torch.Tensor) -> torch.Tensor:

@@ -14,13 +14,42 @@ def cosine_distance_from_gram(G: torch.Tensor) -> np.ndarray:
     nrm = G.diagonal().clamp_min(0).sqrt()
     # torch.cosine_similarity clamps each norm at eps = 1e-8
     denom = nrm.clamp_min(1e-8).unsqueeze(0) * nrm.clamp_min(1e-8).unsqueeze(1)
-    dis = (1.0 - G / denom).double().cpu().numpy()
-    dis[dis == -np.inf] = 0
-    dis[dis == np.inf] = 2
-    dis[np.isnan(dis)] = 2
+    dis = torch.nan_to_num((1.0 - G / denom).double(), nan=2.0, posinf=2.0, neginf=0.0)
     dis = 0.5 * (dis + dis.T)
-    np.fill_diagonal(dis, 0.0)
-    return dis
+    dis.fill_diagonal_(0.0)
+    return dis.cpu().numpy()  # the one device->host copy of the aggregator: K x K doubles for the host clustering
+
+
+class NormHistory:
+    """Every client norm seen so far (reference ``l2norm_his``, ``clippedclustering.py:33-35``) as a device buffer
+    that doubles its capacity: appending and taking the median never leave the device."""
+
+    def __init__(self):
+        self.buf = None
+        self.n = 0
+
+    def extend(self, norms: torch.Tensor):
+        k = norms.numel()
+        if self.buf is None or self.buf.device != norms.device or self.n + k > self.buf.numel():
+            cap = max(2 * (self.n + k), 1024)
+            new = torch.empty(cap, dtype=torch.float32, device=norms.device)
+            if self.n:
+                new[: self.n] = self.buf[: self.n].to(norms.device)
+            self.buf = new
+        self.buf[self.n: self.n + k] = norms.float()
+        self.n += k
+
+    def median(self) -> torch.Tensor:
+        """``numpy.median`` semantics (mean of the two middle values for an even count), 0-d device tensor."""
+        v = self.buf[: self.n]
+        hi = torch.kthvalue(v, self.n // 2 + 1).values
+        return hi if self.n % 2 else 0.5 * (hi + torch.kthvalue(v, self.n // 2).values)
+
+    def tolist(self):
+        return [] if self.buf is None else self.buf[: self.n].tolist()
+
+    def __len__(self):
+        return self.n
 
 
 class Clippedclustering(Aggregator):
@@ -28,10 +57,14 @@ class Clippedclustering(Aggregator):
     distance, keep the majority cluster (optionally ∩ SignGuard's sign
     clustering), then Mean/Median.
 
-    ``l2norm_his`` grows by K every round like the reference (``:33-35``).  The
-    cosine matrix comes from one MFMA Gram GEMM on the clipped rows; the
-    clustering runs in the native host library.
+    ``l2norm_his`` grows by K every round like the reference (``:33-35``) and stays on the device (norms, running
+    median and clip factors are computed without a host sync).  The cosine matrix comes from one MFMA Gram GEMM on the
+    clipped rows and makes the aggregator's single device->host copy; the clustering itself is sequential
+    (K - 1 dependent merges) and runs in the native host library (blades_amd/ops/csrc/host.cpp, nearest-neighbour
+    chain, ~10 ms at K = 1000, 0.3 ms at K = 60).
     """
+
+    mutates_input = True
 
     def __init__(self, agg="mean", signguard=False, max_tau=1e5, linkage="average") -> None:
         super().__init__()
@@ -39,7 +72,7 @@ class Clippedclustering(Aggregator):
         self.tau = max_tau
         self.signguard = signguard
         self.linkage = linkage
-        self.l2norm_his = []
+        self.l2norm_his = NormHistory()
         self.agg = _make_inner(agg)
 
     def aggregate(self, U, ctx):
@@ -51,8 +84,8 @@ class Clippedclustering(Aggregator):
 
             sq, cnt = global_sqnorm(U, ctx), None
         norms = sq.sqrt()
-        self.l2norm_his.extend(norms.tolist())
-        threshold = min(float(np.median(self.l2norm_his)), self.tau)
+        self.l2norm_his.extend(norms)
+        threshold = self.l2norm_his.median().clamp(max=self.tau).to(norms.dtype)
         scale = torch.where(norms > threshold, threshold / norms, torch.ones_like(norms))
         ops.row_scale_(U, scale)
 
@@ -68,7 +101,10 @@ class Clippedclustering(Aggregator):
         return masked_inner(U, sel, self.agg)
 
     def state_dict(self):
-        return {"l2norm_his": list(self.l2norm_his)}
+        return {"l2norm_his": self.l2norm_his.tolist()}
 
     def load_state_dict(self, state):
-        self.l2norm_his = list(state.get("l2norm_his", []))
+        self.l2norm_his = NormHistory()
+        his = state.get("l2norm_his", [])
+        if len(his):
+            self.l2norm_his.extend(torch.tensor(his, dtype=torch.float32))

@@ -36,6 +36,8 @@ class Signguard(Aggregator):
     ``[K,3]`` features go to the native 2-means (``ops.host.kmeans``).
     """
 
+    mutates_input = True
+
     def __init__(self, agg="mean", max_tau=1e5, linkage="average") -> None:
         super().__init__()
         assert linkage in ["average", "single"]

@@ -149,6 +149,9 @@ class Fedavg(Algorithm):
             batch_size=self._dataset.train_bs, seed=config.seed, clients_per_chunk=config.clients_per_chunk,
             amp_dtype=config.amp_dtype, execution_mode=config.execution_mode,
             num_classes=dc.get("num_classes"), update_layout=self.update_layout)
+        if self.engine.D != self.server.D:
+            raise RuntimeError(f"engine and server disagree on the flat model width ({self.engine.D} vs "
+                               f"{self.server.D}): both must enumerate utils.torch_utils.named_trainable_parameters")
         self._malicious_flags = [bool(c.is_malicious) for c in clients]
         self._benign_mask = self.engine.row_mask([not m for m in self._malicious_flags])
         self.num_benign = int(sum(1 for m in self._malicious_flags if not m))  # host copy: no sync to ask

@@ -546,6 +546,10 @@ def supports(model: nn.Module) -> bool:
         own = list(m.parameters(recurse=False))
         if not own:
             continue
+        if _broadcast_params(m) is not None:  # a frozen (sinusoidal) positional embedding stays a shared constant
+            continue
+        if any(not p.requires_grad for p in own):
+            return False  # a frozen layer: the per-client layers write every parameter's gradient
         if isinstance(m, nn.Conv2d) and m.groups == 1 and m.padding_mode == "zeros" and not isinstance(
                 m.padding, str):
             continue
@@ -619,7 +623,9 @@ class FusedFedSGD:
         self.task = task
         self.sink = GradSink()
         self.template = build_template(task.model, self.sink)
-        for (n, p), o, m in zip(task.model.named_parameters(), offsets[:-1], numels):
+        from blades_amd.utils.torch_utils import named_trainable_parameters
+
+        for (n, p), o, m in zip(named_trainable_parameters(task.model), offsets[:-1], numels):
             self.sink.offsets[id(p)] = (int(o), int(m))
         self.amp_dtype = amp_dtype
         self.device = device

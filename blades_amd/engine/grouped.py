@@ -86,6 +86,8 @@ def supports(model: nn.Module) -> bool:
     for m in model.modules():
         if not list(m.parameters(recurse=False)):
             continue
+        if any(not p.requires_grad for p in m.parameters(recurse=False)):
+            return False
         if isinstance(m, nn.Conv2d) and m.groups == 1 and m.padding_mode == "zeros" and not isinstance(m.padding, str):
             continue
         if isinstance(m, nn.Linear):
@@ -188,7 +190,8 @@ class GroupedLocalSGD:
         try:
             g = torch.Generator().manual_seed(0)
             Kc, B = 2, 4
-            flat = torch.cat([p.detach().reshape(-1).float().cpu() for p in self.task.model.parameters()])
+            flat = torch.cat([p.detach().reshape(-1).float().cpu() for p in self.task.model.parameters()
+                              if p.requires_grad])
             W = (flat.unsqueeze(0) * (1.0 + 0.05 * torch.randn(Kc, D, generator=g))).to(self.device)
             X = torch.randn(Kc, B, *sample_shape, generator=g).to(self.device)
             Y = torch.randint(0, num_classes, (Kc, B), generator=g).to(self.device)

@@ -100,8 +100,11 @@ class ClientEngine:
             torch.backends.cudnn.benchmark = True
 
         # ---- parameter layout (named_parameters order == reference flattening)
-        self.names = [n for n, _ in task.model.named_parameters()]
-        self.shapes = [tuple(p.shape) for _, p in task.model.named_parameters()]
+        # trainable parameters only: frozen ones are constants of the model, same enumeration as the server's
+        from blades_amd.utils.torch_utils import named_trainable_parameters
+
+        self.names = [n for n, _ in named_trainable_parameters(task.model)]
+        self.shapes = [tuple(p.shape) for _, p in named_trainable_parameters(task.model)]
         self.numels = [int(np.prod(s)) if len(s) else 1 for s in self.shapes]
         self.offsets = np.concatenate([[0], np.cumsum(self.numels)]).astype(np.int64)
         self.D = int(self.offsets[-1])
@@ -532,8 +535,9 @@ class ClientEngine:
         client = self.clients[self.local_ids[r]]
         w = current_worker()
         with torch.no_grad():
-            torch.nn.utils.vector_to_parameters(theta.to(next(w.task.model.parameters()).device),
-                                                w.task.model.parameters())
+            from blades_amd.utils.torch_utils import vector_to_parameters
+
+            vector_to_parameters(theta.to(next(w.task.model.parameters()).device), w.task.model.parameters())
         res = client.train_one_round(self.dataset.get_train_loader(client.client_id))
         upd = res.get(CLIENT_UPDATE)
         if upd is not None:

@@ -240,16 +240,43 @@ def _order_stat_fill(mask, K: int, mode: int):
     return fill
 
 
+def _col_order_stat_wide(U, mask, mode: int, b: int):
+    """More than 2048 rows (beyond the in-LDS selection network of orderstat.hip): the same statistics from a
+    device radix sort, one column slab at a time so the sorted copy stays under ~1 GB.  Masked rows sort to the
+    top as +inf and the statistic indexes the first ``n`` sorted rows (``n`` stays a device scalar: no sync)."""
+    K, Dl = U.shape
+    out = _empty(Dl, device=U.device)
+    live = None if mask is None else (mask > 0)
+    n = torch.full((), K, device=U.device, dtype=torch.long) if live is None else live.sum()
+    idx = torch.arange(K, device=U.device).unsqueeze(1)
+    step = max(1, (256 << 20) // K)
+    for c0 in range(0, Dl, step):
+        blk = U[:, c0: c0 + step].float()
+        if live is not None:
+            blk = torch.where(live.unsqueeze(1), blk, torch.full((), float("inf"), device=U.device))
+        srt = torch.sort(blk, dim=0).values
+        if mode == 0:  # mean of lower and upper median
+            lo, hi = (n - 1) // 2, n // 2
+            res = 0.5 * (srt.index_select(0, lo.reshape(1)) + srt.index_select(0, hi.reshape(1))).squeeze(0)
+        else:  # mean of sorted rows [b, n - b)
+            keep = (idx >= b) & (idx < n - b)
+            res = torch.where(keep, srt, torch.zeros((), device=U.device)).sum(0) / (n - 2 * b).clamp_min(1)
+        out[c0: c0 + step] = res
+    return out
+
+
 def col_order_stat(U, mask, mode: int, b: int):
     K, Dl, ld = _chk_matrix(U)
     mask = _vec(mask, K, U.device, name="mask")
+    if K > 2048:
+        if mode == 1 and mask is None and not 0 <= 2 * b < K:
+            raise ValueError(f"trimmed mean needs 0 <= 2*b < K, got b={b}, K={K}")
+        return _col_order_stat_wide(U, mask, mode, b)
     if mode == 1 and mask is None and not 0 <= 2 * b < K:
         raise ValueError(f"trimmed mean needs 0 <= 2*b < K, got b={b}, K={K}")
     fill = None if mask is None else _order_stat_fill(mask, K, mode)
     out = _empty(Dl, device=U.device)
     rc = _col_order_stat(_ptr(U), ld, K, Dl, _ptr(fill), K, mode, b, _ptr(out), _stream())
-    if rc == 1:
-        raise ValueError(f"col_order_stat supports up to 2048 rows, got {K}")
     if rc != 0:
         raise ValueError(f"col_order_stat rejected the call (code {rc}): K={K}, ld={ld}, Dl={Dl}, b={b}")
     return out

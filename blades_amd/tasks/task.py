@@ -89,6 +89,8 @@ class Task:
     def compute_psudo_grad(self) -> Dict[str, torch.Tensor]:
         pseudo_grad = {}
         for name, param in self._model.named_parameters():
+            if not param.requires_grad:  # frozen parameters take no columns of the update (utils.torch_utils)
+                continue
             pseudo_grad[name] = param.data - self._saved_state_dict[name]
         self._model.load_state_dict(self._saved_state_dict)
         return pseudo_grad

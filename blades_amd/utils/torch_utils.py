@@ -19,13 +19,29 @@ def set_torch_seed(seed: Optional[int]) -> None:
     os.environ["PYTHONHASHSEED"] = str(seed)
 
 
+def named_trainable_parameters(model: torch.nn.Module):
+    """``(name, parameter)`` of the parameters that make up the flat model / update vector: the trainable ones, in
+    ``named_parameters`` order.  Frozen parameters (a sinusoidal positional embedding, a frozen word embedding) are
+    constants of the model and take no columns — the rule of the reference's flatten helpers and server
+    (fllib/utils/torch_utils.py:145,194, fllib/algorithms/server.py:122-124).  The reference's *client* side still
+    emits columns for them (fllib/tasks/task.py:162-168), which shifts every later parameter's slice on the server;
+    here the engine, the sequential client path and the server all use this one enumeration."""
+    return [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+
+
+def trainable_parameters(model: torch.nn.Module):
+    return [p for _, p in named_trainable_parameters(model)]
+
+
 def parameters_to_vector(parameters: Iterable[torch.Tensor]) -> torch.Tensor:
-    return torch.cat([p.reshape(-1) for p in parameters])
+    return torch.cat([p.reshape(-1) for p in parameters if getattr(p, "requires_grad", True)])
 
 
 def vector_to_parameters(vec: torch.Tensor, parameters: Iterable[torch.Tensor]) -> None:
     pointer = 0
     for p in parameters:
+        if not getattr(p, "requires_grad", True):
+            continue
         n = p.numel()
         p.data.copy_(vec[pointer: pointer + n].view_as(p))
         pointer += n

@@ -193,3 +193,17 @@ def test_geomed_gram_formulation_matches_direct():
     V = torch.cat([U[:5], U[:5].mean(0, keepdim=True)])
     torch.testing.assert_close(GeoMed(method="direct").aggregate(V, ctx), GeoMed(method="gram").aggregate(V, ctx),
                                rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["Signguard", "Clippedclustering"])
+def test_call_does_not_modify_the_callers_tensor(name):
+    """Norm-clipping aggregators rescale rows in place on the engine's resident matrix; ``__call__`` on a
+    user-owned tensor works on a copy (the reference stacks its input list first)."""
+    import blades_amd.aggregators as A
+
+    torch.manual_seed(0)
+    U = torch.randn(12, 40)
+    U[3] *= 50
+    keep = U.clone()
+    getattr(A, name)()(U)
+    assert torch.equal(U, keep)

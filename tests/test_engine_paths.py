@@ -169,3 +169,38 @@ def test_client_keyed_dropout_is_active_and_path_independent(data_root, model, d
     U2, _ = one_round_updates(g2)
     rel = (U1 - U2).norm(dim=1) / U2.norm(dim=1)
     assert float(rel.max()) < 5e-3, rel
+
+
+def _sine_cct():
+    from blades_amd.models import cctnets
+
+    return cctnets.cct_2_3x2_32(positional_embedding="sine")
+
+
+@pytest.mark.parametrize("nb", [1, 2])
+def test_frozen_parameters_take_no_update_columns(data_root, nb):
+    """A frozen parameter (the sinusoidal positional embedding) is a constant of the model: server, engine (fused and
+    vmap), and the sequential client path all flatten the trainable parameters only, so widths and offsets agree
+    (the reference's client emits columns for frozen parameters that its server then skips, fllib/tasks/task.py:162
+    vs fllib/algorithms/server.py:122)."""
+    algos = {}
+    for mode in ("fused", "vmap", "sequential"):
+        torch.manual_seed(0)
+        a = build(data_root, _sine_cct(), mode, nb=nb, lr=0.05)
+        for net in (a.engine.task.model, a.engine.model, a.engine.fused.template if a.engine.fused else None):
+            if net is not None:
+                _no_random_drops(net)
+                net.apply(lambda m: setattr(m, "p", 0.0) if isinstance(m, torch.nn.modules.dropout._DropoutNd) else None)
+        algos[mode] = a
+    a = algos["fused"]
+    frozen = [n for n, p in a.engine.task.model.named_parameters() if not p.requires_grad]
+    assert frozen == ["classifier.positional_emb"]
+    n_train = sum(p.numel() for p in a.engine.task.model.parameters() if p.requires_grad)
+    assert a.engine.D == a.server.D == n_train
+    assert a.engine.fused is not None
+    pe0 = a.engine.task.model.classifier.positional_emb.clone()
+    res = {m: one_round_updates(al) for m, al in algos.items()}
+    torch.testing.assert_close(res["fused"][0], res["vmap"][0], rtol=2e-3, atol=2e-5)
+    if nb == 1:  # sequential clients draw their batches from a DataLoader-like reader with the same sampler
+        assert res["sequential"][0].shape == res["vmap"][0].shape
+    assert torch.equal(a.engine.task.model.classifier.positional_emb, pe0)

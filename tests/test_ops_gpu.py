@@ -72,6 +72,11 @@ def test_median_trimmed(dev, K, D):
                                atol=1e-5)
 
 
+def test_median_trimmed_beyond_2048_rows(dev):
+    """K > 2048 leaves the in-LDS selection network for the slab-wise device sort (ops/_hip.py)."""
+    test_median_trimmed(dev, 2304, 1000)
+
+
 def test_median_oracle_4x3(dev):
     U = torch.tensor([[1, 2, 3], [-1, 4, -1], [2.0, 2, 3], [3.0, 1.0, 3]], device=dev)
     torch.testing.assert_close(ops.col_median(U), torch.tensor([1.5, 2.0, 3.0], device=dev))
