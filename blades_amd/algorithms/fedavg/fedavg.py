@@ -223,6 +223,9 @@ class Fedavg(Algorithm):
 
     # ------------------------------------------------------------------
     def training_step(self):
+        from blades_amd.parallel.runtime import heartbeat
+
+        heartbeat(f"round {self.engine.round}")  # stall watchdog of the launcher; a no-op without one
         T = self._timers
         with T("local_train"):
             U, loss_sum, loss_cnt = self.engine.train_round(self.server.theta)

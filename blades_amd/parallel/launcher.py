@@ -10,6 +10,10 @@ Two front ends over the same contract — every rank gets ``RANK``, ``LOCAL_RANK
 
 A rank that fails takes the others down (SIGTERM to the exact child pids, SIGKILL after a grace
 period), so a dead rank cannot leave its peers blocked in an RCCL collective until the watchdog fires.
+A rank that *hangs* (stuck kernel, deadlocked collective) is caught by the stall watchdog: ranks mark progress
+through :func:`blades_amd.parallel.runtime.heartbeat` (once per FL round); with ``stall_timeout_s`` set, a rank that
+has started beating and then stays silent that long ends the job with status 124 and a line naming the rank and
+its last mark — the replacement for Ray's actor health probes (``fllib/core/execution/actor_manager.py``).
 """
 import argparse
 import os
@@ -17,6 +21,7 @@ import signal
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 from typing import List, Optional, Sequence
 
@@ -30,8 +35,11 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def rank_env(rank: int, world: int, addr: str, port: int, pin_gpus: bool = False) -> dict:
+def rank_env(rank: int, world: int, addr: str, port: int, pin_gpus: bool = False,
+             heartbeat_dir: Optional[str] = None) -> dict:
     env = dict(os.environ)
+    if heartbeat_dir:
+        env["BLADES_HEARTBEAT_DIR"] = heartbeat_dir
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR=addr, MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -41,14 +49,40 @@ def rank_env(rank: int, world: int, addr: str, port: int, pin_gpus: bool = False
 
 
 def launch(cmd: Sequence[str], nproc: int, master_addr: str = "127.0.0.1", master_port: Optional[int] = None,
-           pin_gpus: bool = False, grace_s: float = 10.0, poll_s: float = 0.05) -> int:
-    """Run ``cmd`` as ``nproc`` ranks; returns the first non-zero exit status (0 if all succeed)."""
+           pin_gpus: bool = False, grace_s: float = 10.0, poll_s: float = 0.05,
+           stall_timeout_s: Optional[float] = None) -> int:
+    """Run ``cmd`` as ``nproc`` ranks; returns the first non-zero exit status (0 if all succeed, 124 if the stall
+    watchdog ended the job)."""
     port = master_port or free_port()
+    if stall_timeout_s is None and os.environ.get("BLADES_STALL_TIMEOUT_S"):
+        stall_timeout_s = float(os.environ["BLADES_STALL_TIMEOUT_S"])
+    hb = tempfile.TemporaryDirectory(prefix="blades_hb_") if stall_timeout_s else None
     procs: List[subprocess.Popen] = [
-        subprocess.Popen(list(cmd), env=rank_env(r, nproc, master_addr, port, pin_gpus)) for r in range(nproc)]
+        subprocess.Popen(list(cmd), env=rank_env(r, nproc, master_addr, port, pin_gpus, hb.name if hb else None))
+        for r in range(nproc)]
     code, deadline = 0, None
+    next_check = time.time() + 1.0
     try:
         while any(p.poll() is None for p in procs):
+            if hb is not None and code == 0 and time.time() >= next_check:
+                next_check = time.time() + min(1.0, stall_timeout_s / 4)
+                for r, p in enumerate(procs):
+                    path = os.path.join(hb.name, f"rank{r}")
+                    if p.poll() is not None or not os.path.exists(path):
+                        continue  # finished, or still starting up (first mark comes from init_runtime)
+                    quiet = time.time() - os.path.getmtime(path)
+                    if quiet > stall_timeout_s:
+                        try:
+                            tag = open(path).read()
+                        except OSError:
+                            tag = "?"
+                        print(f"[launcher] rank {r} (pid {p.pid}) made no progress for {quiet:.0f} s "
+                              f"(last mark: {tag!r}); ending the job", file=sys.stderr)
+                        code, deadline = 124, time.time() + grace_s
+                        for q in procs:
+                            if q.poll() is None:
+                                q.send_signal(signal.SIGTERM)
+                        break
             for r, p in enumerate(procs):
                 rc = p.poll()
                 if rc not in (None, 0) and code == 0:
@@ -73,6 +107,8 @@ def launch(cmd: Sequence[str], nproc: int, master_addr: str = "127.0.0.1", maste
         rc = p.wait()
         if rc != 0 and code == 0:
             code = rc if rc > 0 else 128 - rc
+    if hb is not None:
+        hb.cleanup()
     return code
 
 
@@ -94,6 +130,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("--master-addr", default="127.0.0.1")
     ap.add_argument("--master-port", type=int, default=None)
     ap.add_argument("--pin-gpus", action="store_true", help="one visible GPU per rank (HIP_VISIBLE_DEVICES)")
+    ap.add_argument("--stall-timeout", type=float, default=None,
+                    help="seconds without a progress mark from a rank before the job is ended (status 124)")
     ap.add_argument("--native", action="store_true", help="hand over to the C++ launcher")
     ap.add_argument("cmd", nargs=argparse.REMAINDER, help="-- program [args...]; a .py file is run with this python")
     a = ap.parse_args(argv)
@@ -105,9 +143,10 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     if a.native:
         exe = build_native()
         full = [exe, "--nproc", str(a.nproc_per_node), "--master-addr", a.master_addr, "--master-port",
-                str(a.master_port or free_port())] + (["--pin-gpus"] if a.pin_gpus else []) + ["--"] + cmd
+                str(a.master_port or free_port())] + (["--pin-gpus"] if a.pin_gpus else []) + (
+                    ["--stall-timeout", str(int(a.stall_timeout))] if a.stall_timeout else []) + ["--"] + cmd
         return subprocess.call(full)
-    return launch(cmd, a.nproc_per_node, a.master_addr, a.master_port, a.pin_gpus)
+    return launch(cmd, a.nproc_per_node, a.master_addr, a.master_port, a.pin_gpus, stall_timeout_s=a.stall_timeout)
 
 
 if __name__ == "__main__":

@@ -38,11 +38,31 @@ class Runtime:
 _runtime: Optional[Runtime] = None
 
 
-def init_runtime(use_gpu: Optional[bool] = None, timeout_s: int = 600) -> Runtime:
+def heartbeat(tag: str = "") -> None:
+    """Progress mark of this rank for the launcher's stall watchdog (``launcher.launch(stall_timeout_s=...)``):
+    rewrites ``$BLADES_HEARTBEAT_DIR/rank<r>`` with the tag.  A no-op (one dict lookup) without a watchdog.  The
+    algorithm calls it once per round, so a rank stuck in a kernel or waiting in a collective for a stuck peer stops
+    beating and the launcher ends the job, naming the rank — long before the process group's own collective
+    timeout (``BLADES_COLLECTIVE_TIMEOUT_S``, default 600 s), which stays as the backstop."""
+    d = os.environ.get("BLADES_HEARTBEAT_DIR")
+    if not d:
+        return
+    try:
+        path = os.path.join(d, f"rank{os.environ.get('RANK', '0')}")
+        with open(path + ".tmp", "w") as f:
+            f.write(tag)
+        os.replace(path + ".tmp", path)
+    except OSError:
+        pass
+
+
+def init_runtime(use_gpu: Optional[bool] = None, timeout_s: Optional[int] = None) -> Runtime:
     """Idempotent.  ``use_gpu=None`` -> GPU iff one is visible."""
     global _runtime
     if _runtime is not None:
         return _runtime
+    if timeout_s is None:
+        timeout_s = int(os.environ.get("BLADES_COLLECTIVE_TIMEOUT_S", "600"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -68,6 +88,7 @@ def init_runtime(use_gpu: Optional[bool] = None, timeout_s: int = 600) -> Runtim
                                     timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
             owns = True
     _runtime = Runtime(rank, world, local_rank, device, backend, owns)
+    heartbeat("init")
     return _runtime
 
 

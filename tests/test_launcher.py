@@ -60,3 +60,28 @@ def test_launch_two_rank_allreduce(tmp_path):
     rc = subprocess.call([sys.executable, "-m", "blades_amd.parallel.launcher", "--nproc", "2", "--", str(p)],
                          cwd=ROOT, env=env)
     assert rc == 0
+
+
+def test_stall_watchdog_ends_a_hung_job(capfd):
+    """A rank that stops marking progress (hung kernel / collective) ends the job with status 124 after
+    ``stall_timeout_s`` — not after the process group's 600 s collective timeout."""
+    import time
+
+    from blades_amd.parallel.launcher import launch
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_stall_worker.py")
+    t0 = time.time()
+    rc = launch([sys.executable, worker], 2, stall_timeout_s=2.0, grace_s=2.0)
+    assert rc == 124
+    assert time.time() - t0 < 30
+    err = capfd.readouterr().err
+    assert "rank 1" in err and "no progress" in err
+
+
+def test_native_stall_watchdog(capfd):
+    exe = launcher.build_native()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_stall_worker.py")
+    t0 = time.time()
+    rc = subprocess.call([exe, "--nproc", "2", "--stall-timeout", "2", "--grace", "2", "--", sys.executable, worker])
+    assert rc == 124 and time.time() - t0 < 30
+    assert "rank 1" in capfd.readouterr().err
