@@ -665,6 +665,8 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
     # time plus the slab's write + read traffic.
     blocks = Kc * (Cout // (tmt * 16)) * n_ci_tiles
     slots, t_step, bw = 512, 1.5e-6, 4e12
+    if npl > 1:  # split planes: one resident block per CU (the plane images fill LDS), 3 / 6 MFMA products per step
+        slots, t_step = 256, (3.2e-6 if npl == 3 else 1.8e-6)
     best, split = None, 1
     for sp in range(1, max(1, min(16, plan["nsteps"] // 16)) + 1):
         waves = -(-blocks * sp // slots)

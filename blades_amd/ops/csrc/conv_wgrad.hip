@@ -16,7 +16,7 @@
 //    MFMA operands are transposed on the way out of LDS with ds_read_b64_tr_b16: LDS images are
 //    [16-channel block][pixel][16 ch] (32 B per pixel), a lane group fetches 4 consecutive
 //    pixels ("quad") of its channel.  A K-step is 32 output pixels = 8 quads; one half-wave reads
-//    two adjacent quads = 256 contiguous bytes -> conflict-free.
+//    two adjacent quads = 256 contiguous bytes -> conflict-free (PMC: 0.7 M conflict cycles with staging off).
 //  * x is staged as whole input rows in a circular line buffer (each input row is loaded once
 //    per block and reused by all taps and by the neighbouring output rows); the 9 shifted
 //    windows are just different LDS offsets.  Stride-2 convs store a row de-interleaved by
@@ -150,10 +150,16 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
   const int c = rest % p.Kc, zsplit = rest / p.Kc;
   const int co0 = (tile / n_ci_tiles) * (TMT * 16);
   const int ci0 = (tile % n_ci_tiles) * 64;
-  constexpr int GYB = TMT * 1024;                        // one gy tile of one plane: [TMT][32 px][16 co] bf16
+  // LDS stores are banked over 128 B in groups of 8 lanes = the 8 channel chunks of one pixel, i.e. four 32-byte
+  // pieces one per 16-channel block: block images sit at odd multiples of 32 B (mod 128) from each other (GYM below,
+  // the +32 of plane_bytes) or all four pieces land on the same 8 banks.  Measured with the kernel's ablation
+  // switches (profiles/r2_pmc_hot_kernels.txt): every bank-conflict cycle of this kernel came from these stores
+  // (4-way, 24 M cycles of 58 M LDS cycles); the transposed fragment reads are conflict-free.
+  constexpr int GYM = 1024 + 32;                         // one 16-co block of a gy tile: [32 px][16 co] bf16 + pad
+  constexpr int GYB = TMT * GYM;                         // one gy tile of one plane
   unsigned char* gy_lds = smem;                          // [2][NPL][TMT][32 px][16 co] bf16
   unsigned char* x_lds = smem + 2 * NPL * GYB;           // [NPL][4 ci-blocks][nlines][wslots][16 ci] bf16
-  const int plane_bytes = (p.nlines + 1) * p.wslots * 32;  // ring of nlines + one all-zero line (index nlines)
+  const int plane_bytes = (p.nlines + 1) * p.wslots * 32 + 32;  // ring of nlines + one all-zero line (index nlines)
   const int xpl_bytes = 4 * plane_bytes;                 // one precision plane of the x image
   const int line_mask = p.nlines - 1;
 
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
   };
   auto commit = [&](int s, const Stg& rg, int row_lo, int row_hi) {
     if (chunk < TMT * 2)
-      put(gy_lds + (s & 1) * NPL * GYB + (chunk >> 1) * 1024 + pix * 32 + (chunk & 1) * 16, GYB, rg.gy);
+      put(gy_lds + (s & 1) * NPL * GYB + (chunk >> 1) * GYM + pix * 32 + (chunk & 1) * 16, GYB, rg.gy);
     const int npix = (row_hi - row_lo + 1) * p.W;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
@@ -364,8 +370,8 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
       for (int q = 0; q < NPL; ++q)
 #pragma unroll
         for (int m = 0; m < TMT; ++m) {
-          const i32x2 lo = tr_read(gy_buf + q * GYB + m * 1024 + (0 * 16 + g * 4) * 32);
-          const i32x2 hi = tr_read(gy_buf + q * GYB + m * 1024 + (1 * 16 + g * 4) * 32);
+          const i32x2 lo = tr_read(gy_buf + q * GYB + m * GYM + (0 * 16 + g * 4) * 32);
+          const i32x2 hi = tr_read(gy_buf + q * GYB + m * GYM + (1 * 16 + g * 4) * 32);
           a[q][m] = i32x4{lo[0], lo[1], hi[0], hi[1]};
         }
 #pragma unroll
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
             it.v[l] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) + 16 * l);
         }
         if (chunk < TMT * 2)
-          put(gy_lds + (s_begin & 1) * NPL * GYB + (chunk >> 1) * 1024 + pix * 32 + (chunk & 1) * 16, GYB, it);
+          put(gy_lds + (s_begin & 1) * NPL * GYB + (chunk >> 1) * GYM + pix * 32 + (chunk & 1) * 16, GYB, it);
       }
     }
     load_desc(s_begin);
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 template <int TMT, int KS, int MAXP, int NPF, bool FAST, int NPL>
 int launch(const WgradParams& p, int Kc, hipStream_t st) {
-  size_t lds = NPL * (2 * TMT * 1024 + 4 * (size_t)(p.nlines + 1) * p.wslots * 32);
+  size_t lds = NPL * (2 * TMT * (1024 + 32) + 4 * ((size_t)(p.nlines + 1) * p.wslots * 32 + 32));
   const size_t lds_epilogue = 4 * 16 * (16 * KS * KS + 4) * sizeof(float);  // LDS-transposed write-out
   if (KS > 1 && lds < lds_epilogue) lds = lds_epilogue;
   if (lds > 160 * 1024) return 3;
