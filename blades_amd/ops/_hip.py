@@ -498,7 +498,7 @@ def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block,
 # ---------------------------------------------------------------------------
 # per-client conv weight gradient
 _conv_wgrad = _sig("blades_conv_wgrad", [_P, _P, _P, c_long, c_long, _P, c_int] + [c_int] * 11 + [_P] + [c_int] * 5
-                   + [_P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, c_int, _P], c_int)
+                   + [_P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, c_int, c_int, _P], c_int)
 _wgrad_plans = {}
 
 
@@ -645,6 +645,35 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
         x, Cin = xp, 16
     x_client_stride = B * H * W * Cin
     rmul, cmul = W, 1
+    if npl > 1 and ks == 3 and stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0:
+        # fp32 planes: the split images of a strided layer's input window do not fit in LDS.  The layer is posed as
+        # four stride-1 problems, one per parity class x[:, p::2, q::2] of the input (addressed in place), in one
+        # grid; each class computes only the taps it owns (4 + 2 + 2 + 1 = 9) — see blades_conv_wgrad.
+        plan = _wgrad_plan(B, Ho, Wo, Ho, Wo, 3, 1, 1, x.device)
+        if plan["passes"] > 1:
+            return False
+        tmt = 4
+        while tmt > 1 and Cout % (tmt * 16):
+            tmt //= 2
+        blocks = 4 * Kc * (Cout // (tmt * 16)) * (-(-Cin // 64))
+        slots, bw = 256, 4e12
+        t_step = (3.2e-6 if npl == 3 else 1.8e-6) * 0.45  # 9/4 taps per block on average + per-step overhead
+        best, split = None, 1
+        for sp in range(1, max(1, min(16, plan["nsteps"] // 16)) + 1):
+            waves = -(-blocks * sp // slots)
+            est = waves / sp * plan["nsteps"] * t_step + (0.0 if sp == 1 else (sp + 1) * Kc * numel * 4 / bw)
+            if best is None or est < best * 0.97:
+                best, split = est, sp
+        scratch = _scratch(split * Kc * numel, x.device) if split > 1 else None
+        rc = _conv_wgrad(_ptr(x), _ptr(gy), _ptr(U_block), ld, off, _ptr(coef), int(accumulate), Kc, B, Ho, Wo, Cin, Ho,
+                         Wo, Cout, 3, 1, 1, _ptr(plan["table"]), plan["nsteps"], plan["nlines"], plan["wslots"], tmt,
+                         split, _ptr(scratch), 2 * W, 2, plan["passes"], plan["rows_r"], plan["rows_off"],
+                         x_client_stride, cin_store, npl, 1, _stream())
+        if rc == 3:
+            return False
+        if rc != 0:
+            raise ValueError(f"conv_wgrad_: strided layer as parity classes rejected (rc={rc})")
+        return True
     if ks == 1 and pad == 0 and stride > 1:
         # a strided 1x1 conv only ever touches x[:, ::s, ::s]: run it as a stride-1 1x1 conv on that
         # virtual sub-image (addressed in place, nothing is copied)
@@ -679,7 +708,7 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
     rc = _conv_wgrad(_ptr(x), _ptr(gy), _ptr(U_block), ld, off, _ptr(coef), int(accumulate), Kc, B, H, W, Cin, Ho,
                      Wo, Cout, ks, stride, pad, _ptr(plan["table"]), plan["nsteps"], plan["nlines"], plan["wslots"],
                      tmt, split, _ptr(scratch), rmul, cmul, plan["passes"], plan["rows_r"], plan["rows_off"], x_client_stride,
-                     cin_store, npl, _stream())
+                     cin_store, npl, 0, _stream())
     if rc == 3:  # staging does not fit in LDS
         return False
     if rc != 0:

@@ -82,6 +82,7 @@ struct WgradParams {
   int Cs;               // input channels actually stored (< Cin when x was zero-padded to a multiple of 16)
   int ablate;           // diagnostics only (BLADES_WGRAD_ABLATE): bit0 skip staging after the prologue, bit1 skip
                         // the MFMA work, bit2 no rotation of the step range
+  int s2_classes;       // MASKED variant: the four parity classes of a stride-2 3x3 layer in one grid (see the API)
 };
 
 // 4 consecutive k (pixels) of this lane's channel, as two packed-bf16 dwords (kept as 32-bit lanes so
@@ -131,7 +132,7 @@ __device__ __forceinline__ void split8(const u32x4 lo, const u32x4 hi, u32x4 (&p
   }
 }
 
-template <int TMT, int KS, int MAXP, int NPF, bool FAST, int NPL>
+template <int TMT, int KS, int MAXP, int NPF, bool FAST, int NPL, bool MASKED = false>
 __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int TAPS = KS * KS;
   using elem_t = std::conditional_t<NPL == 1, unsigned short, float>;
@@ -148,8 +149,27 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
   const int n_ci_tiles = (p.Cin + 63) >> 6;
   const int tile = lid % p.ntiles, rest = lid / p.ntiles;
   const int c = rest % p.Kc, zsplit = rest / p.Kc;
-  const int co0 = (tile / n_ci_tiles) * (TMT * 16);
-  const int ci0 = (tile % n_ci_tiles) * 64;
+  // MASKED: a (co, ci) tile exists once per parity class; class = (row parity, column parity) of the input pixels.
+  // The class's input is x[:, rp::2, cp::2] (rmul / cmul address it in place); kernel row r of the stride-1 problem
+  // it poses is the layer's kernel row 2r (odd rows, r = 0, 1) or 1 (even rows, r = 1) — same for columns — so the
+  // class owns 4, 2, 2 or 1 of the 9 taps, computes only those and stores only those.
+  const int n_cls_tiles = MASKED ? 4 * n_ci_tiles : n_ci_tiles;
+  const int co0 = (tile / n_cls_tiles) * (TMT * 16);
+  const int cls = MASKED ? (tile % n_cls_tiles) / n_ci_tiles : 0;
+  const int ci0 = ((tile % n_cls_tiles) % n_ci_tiles) * 64;
+  const int rp = cls >> 1, cp = cls & 1;
+  const int row_bits = rp ? 3 : 2, col_bits = cp ? 3 : 2;  // kernel rows / columns (of the stride-1 problem) in use
+  int tap_mask = 0x1ff;
+  if constexpr (MASKED) {
+    tap_mask = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if ((row_bits >> r) & 1) tap_mask |= col_bits << (r * 3);
+  }
+  auto tap_dst = [&](int t) {  // where tap t of the class goes in the layer's 3x3 filter
+    const int r = t / 3, sx = t - r * 3;
+    return (rp ? 2 * r : 1) * 3 + (cp ? 2 * sx : 1);
+  };
   // LDS stores are banked over 128 B in groups of 8 lanes = the 8 channel chunks of one pixel, i.e. four 32-byte
   // pieces one per 16-channel block: block images sit at odd multiples of 32 B (mod 128) from each other (GYM below,
   // the +32 of plane_bytes) or all four pieces land on the same 8 banks.  Measured with the kernel's ablation
@@ -165,7 +185,8 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
 
   for (int i = tid * 16; i < NPL * xpl_bytes; i += 256 * 16) *reinterpret_cast<u32x4*>(x_lds + i) = u32x4{0, 0, 0, 0};
 
-  const elem_t* xc = reinterpret_cast<const elem_t*>(p.x) + (size_t)c * p.x_client_stride;
+  const elem_t* xc = reinterpret_cast<const elem_t*>(p.x) + (size_t)c * p.x_client_stride +
+                     (MASKED ? (size_t)(rp * (p.rmul >> 1) + cp) * p.Cin : (size_t)0);
   const elem_t* gc = reinterpret_cast<const elem_t*>(p.gy) + (size_t)c * p.B * p.Ho * p.Wo * p.Cout;
 
   // ---- staging roles: 8 lanes x 16 B cover one pixel's 64-channel tile --------------------
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
         }
 #pragma unroll
       for (int r = 0; r < KS; ++r) {
-        if (r + 1 < KS) {
+        if (r + 1 < KS && (!MASKED || ((tap_mask >> ((r + 1) * KS)) & ((1 << KS) - 1)))) {
 #pragma unroll
           for (int q = 0; q < NPL; ++q)
 #pragma unroll
@@ -388,6 +409,7 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sx = 0; sx < KS; ++sx) {
+          if (MASKED && !((tap_mask >> (r * KS + sx)) & 1)) continue;  // block-uniform
           bf16x8 b[NPL];
 #pragma unroll
           for (int q = 0; q < NPL; ++q) {
@@ -507,10 +529,18 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
 #pragma unroll
     for (int m = 0; m < TMT; ++m) {
       __syncthreads();  // previous pass read out / K loop done with the staging buffers
+      if constexpr (MASKED) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) tile[(g * 4 + q) * SEGP + li * TAPS + t] = cf * acc[m][t][q];
+          for (int t = 0; t < TAPS; ++t)
+            if ((tap_mask >> t) & 1) tile[(g * 4 + q) * SEGP + li * TAPS + tap_dst(t)] = cf * acc[m][t][q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) tile[(g * 4 + q) * SEGP + li * TAPS + t] = cf * acc[m][t][q];
+      }
       __syncthreads();
       float* dst0 = row + ((size_t)(co0 + m * 16) * p.Cin + ci0 + wave * 16) * TAPS;
 #pragma unroll
@@ -519,7 +549,12 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
         const int r = f / SEG, col = f - r * SEG;
         float* d = dst0 + (size_t)r * p.Cin * TAPS + col;
         const float v = tile[r * SEGP + col];
-        *d = accum ? *d + v : v;
+        if constexpr (MASKED) {  // only the taps this class owns (the other classes write the rest)
+          const int k = col % TAPS, kr = k / 3, kc = k - kr * 3;
+          if ((kr == 1) == (rp == 0) && (kc == 1) == (cp == 0)) *d = accum ? *d + v : v;
+        } else {
+          *d = accum ? *d + v : v;
+        }
       }
     }
     return;
@@ -533,10 +568,20 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
         const int co = co0 + m * 16 + g * 4 + q;
         if (co < p.Cout && ci < p.Cs) {
           float* dst = row + ((size_t)co * p.Cs + ci) * TAPS;
+          if constexpr (MASKED) {
 #pragma unroll
-          for (int t = 0; t < TAPS; ++t) {
-            const float v = cf * acc[m][t][q];
-            dst[t] = accum ? dst[t] + v : v;
+            for (int t = 0; t < TAPS; ++t)
+              if ((tap_mask >> t) & 1) {
+                const float v = cf * acc[m][t][q];
+                float* d = dst + tap_dst(t);
+                *d = accum ? *d + v : v;
+              }
+          } else {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+              const float v = cf * acc[m][t][q];
+              dst[t] = accum ? dst[t] + v : v;
+            }
           }
         }
       }
@@ -556,7 +601,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-template <int TMT, int KS, int MAXP, int NPF, bool FAST, int NPL>
+template <int TMT, int KS, int MAXP, int NPF, bool FAST, int NPL, bool MASKED = false>
 int launch(const WgradParams& p, int Kc, hipStream_t st) {
   size_t lds = NPL * (2 * TMT * (1024 + 32) + 4 * ((size_t)(p.nlines + 1) * p.wslots * 32 + 32));
   const size_t lds_epilogue = 4 * 16 * (16 * KS * KS + 4) * sizeof(float);  // LDS-transposed write-out
@@ -564,16 +609,16 @@ int launch(const WgradParams& p, int Kc, hipStream_t st) {
   if (lds > 160 * 1024) return 3;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST, NPL>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST, NPL, MASKED>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int n_ci_tiles = (p.Cin + 63) / 64, n_co_tiles = p.Cout / (TMT * 16);
   WgradParams q = p;
-  q.ntiles = n_co_tiles * n_ci_tiles;
+  q.ntiles = n_co_tiles * n_ci_tiles * (MASKED ? 4 : 1);
   q.total_blocks = q.ntiles * Kc * p.split;
   const int grid = (q.total_blocks + 7) / 8 * 8;
-  hipLaunchKernelGGL((conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST, NPL>), dim3(grid), dim3(256), lds, st, q);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST, NPL, MASKED>), dim3(grid), dim3(256), lds, st, q);
   if (p.split > 1) {
     int gx = cdiv(p.numel, 256 * 4);
     if (gx > 1024) gx = 1024;
@@ -590,8 +635,15 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
                                  int accumulate, int Kc, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
                                  int ks, int stride, int pad, const int* table, int nsteps, int nlines, int wslots,
                                  int tmt, int split, float* scratch, int rmul, int cmul, int passes, int rows_r, int rows_off,
-                                 long x_client_stride, int cin_store, int npl, hipStream_t st) {
+                                 long x_client_stride, int cin_store, int npl, int s2_classes, hipStream_t st) {
+  // s2_classes: the call is a stride-2 3x3 pad-1 layer posed as four stride-1 problems in one grid, one per parity
+  // class of the input pixels (H, W, Ho, Wo are then all the *output* size, rmul = 2 * full width, cmul = 2); every
+  // class computes and stores only the taps it owns (4 + 2 + 2 + 1 = 9), so the layer costs its own MFMA work, and
+  // the classes of one client run side by side on one XCD and share its gy rows through L2.  Used for the fp32
+  // planes, whose strided input window does not fit in LDS.
   if (npl < 1 || npl > 3) return 8;
+  const bool masked = s2_classes != 0;
+  if (masked && (ks != 3 || stride != 1 || pad != 1 || passes > 1 || npl == 1 || cmul != 2)) return 9;
   if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || Cin % 16 || Cout % 16) return 1;
   if (nlines & (nlines - 1)) return 2;
   if (cin_store < 1 || cin_store > Cin) return 7;
@@ -607,6 +659,7 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
   p.Cs = cin_store;
   if (p.split > 1 && scratch == nullptr) return 6;
   { const char* e = getenv("BLADES_WGRAD_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+  p.s2_classes = masked ? 1 : 0;
   if (Cout % (tmt * 16)) return 4;
   // power-of-two output geometry -> descriptor-free K loop
   const int qpr = (Wo + 3) / 4;
@@ -627,6 +680,13 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
     if (npl == 2) GO2(T, K, 2);   \
     GO2(T, K, 3);                 \
   } while (0)
+#define GOM(T)                                                                                              \
+  do {                                                                                                      \
+    if (npl == 2) return fast ? launch<T, 3, 1, 3, true, 2, true>(p, Kc, st) : launch<T, 3, 1, 2, false, 2, true>(p, Kc, st); \
+    return fast ? launch<T, 3, 1, 3, true, 3, true>(p, Kc, st) : launch<T, 3, 1, 2, false, 3, true>(p, Kc, st);               \
+  } while (0)
+  if (masked) { if (tmt == 4) GOM(4); if (tmt == 2) GOM(2); GOM(1); }
+#undef GOM
   if (ks == 3) { if (tmt == 4) GO(4, 3); if (tmt == 2) GO(2, 3); if (tmt == 1) GO(1, 3); }
   else { if (tmt == 4) GO(4, 1); if (tmt == 2) GO(2, 1); if (tmt == 1) GO(1, 1); }
 #undef GO
