@@ -455,6 +455,69 @@ class PCLayerNorm(nn.Module):
         return _PCLayerNormFn.apply(x, self)
 
 
+class _MHAFn(torch.autograd.Function):
+    """Fused attention core (ops/csrc/mha.hip): scores, softmax, client-keyed dropout and the value product of every
+    (sample, head) in one kernel; backward recomputes the probabilities from the saved row log-sum-exp."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, scale, drop, npl):
+        h = _hipmod()
+        uids, tag, seed, layer, p = drop if drop is not None else (None, None, 0, 0, 0.0)
+        o, lse = h.mha_forward(qkv, B, scale, uids, tag, seed, layer, p, npl)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.cfg = (B, scale, uids, tag, seed, layer, p, npl)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o, lse = ctx.saved_tensors
+        B, scale, uids, tag, seed, layer, p, npl = ctx.cfg
+        return _hipmod().mha_backward(qkv, o, d_o, lse, B, scale, uids, tag, seed, layer, p, npl), None, None, None, None
+
+
+class PCAttention(nn.Module):
+    """``cctnets.layers.Attention`` with the softmax(q k^T) v core on the fused kernel.  Child names and order are
+    the original's (qkv, attn_drop, proj, proj_drop), so ``swap_dropout`` numbers the dropout layers identically in
+    every structural copy of the model and the mask keys match the other execution paths."""
+
+    def __init__(self, attn: nn.Module, sink: GradSink):
+        super().__init__()
+        self.num_heads, self.scale, self.sink = attn.num_heads, attn.scale, sink
+        self.qkv = attn.qkv
+        self.attn_drop = attn.attn_drop
+        self.proj = attn.proj
+        self.proj_drop = attn.proj_drop
+
+    def _drop_cfg(self):
+        d = self.attn_drop
+        p = float(getattr(d, "p", 0.0))
+        if not self.training or p <= 0.0:
+            return None, True
+        ctx = getattr(d, "ctx", None)
+        if ctx is None:  # a plain nn.Dropout (no engine context): torch path keeps its semantics
+            return None, False
+        if not ctx.enabled or ctx.uids is None:
+            return None, True
+        if ctx.layout != "major" or getattr(d, "kind", "elem") != "elem":
+            return None, False
+        return (ctx.uids, ctx.tag, ctx.seed, d.layer, p), True
+
+    def forward(self, x):
+        Bn, N, C = x.shape
+        H = self.num_heads
+        qkv = self.qkv(x)
+        drop, ok = self._drop_cfg()
+        q5 = qkv.reshape(Bn, N, 3, H, C // H)
+        if ok and x.is_cuda and _os.environ.get("BLADES_DISABLE_HIP_MHA") != "1" and _hipmod().mha_supported(q5) \
+                and Bn % max(self.sink.Kc, 1) == 0:
+            o = _MHAFn.apply(q5, Bn // max(self.sink.Kc, 1), float(self.scale), drop, self.sink.npl)
+        else:
+            q, k, v = q5.permute(2, 0, 3, 1, 4)
+            attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))
+            o = (attn @ v).transpose(1, 2).reshape(Bn, N, C)
+        return self.proj_drop(self.proj(o))
+
+
 class _PCBroadcastFn(torch.autograd.Function):
     """``p`` ([1, ...], shared by every sample) expanded over the batch; backward leaves each client's sum of the
     incoming gradient in its update row."""
@@ -578,6 +641,12 @@ def _broadcast_params(m: nn.Module):
     return None
 
 
+def _cct_attention():
+    from blades_amd.models.cctnets.layers import Attention
+
+    return Attention
+
+
 def build_template(model: nn.Module, sink: GradSink) -> nn.Module:
     memo = {id(p): p for p in model.parameters()}
     tmpl = copy.deepcopy(model, memo)
@@ -592,6 +661,9 @@ def build_template(model: nn.Module, sink: GradSink) -> nn.Module:
                 setattr(mod, name, PCBatchNorm2d(child, sink))
             elif isinstance(child, nn.LayerNorm):
                 setattr(mod, name, PCLayerNorm(child, sink))
+            elif isinstance(child, _cct_attention()):
+                swap(child)  # its Linear layers first
+                setattr(mod, name, PCAttention(child, sink))
             else:
                 names = _broadcast_params(child)
                 for pn in names or []:

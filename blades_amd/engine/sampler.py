@@ -41,18 +41,13 @@ class DeviceSampler:
             self._reshuffle(np.arange(self.K))
 
     def _reshuffle(self, rows: np.ndarray):
-        from blades_amd.ops.reference import _philox4x32
+        from blades_amd import ops
 
         r = torch.as_tensor(rows, device=self.device)
-        pos = torch.arange(self.nmax, dtype=torch.int64, device=self.device).unsqueeze(0).expand(len(rows), -1)
-        uid = torch.as_tensor(self.uids[rows], device=self.device).unsqueeze(1).expand_as(pos)
-        ep = torch.as_tensor(self.epoch[rows], device=self.device).unsqueeze(1).expand_as(pos)
-        w = _philox4x32(pos, uid & 0xFFFFFFFF, ep & 0xFFFFFFFF, torch.full_like(pos, 7), self.seed & 0xFFFFFFFF,
-                        (self.seed >> 32) & 0xFFFFFFFF)
-        keys = (w[0] * 4294967296 + w[1]).double() / float(2 ** 64)  # 64-bit keys: ties are negligible
+        uid = torch.as_tensor(self.uids[rows], device=self.device)
+        ep = torch.as_tensor(self.epoch[rows], device=self.device)
+        keys = ops.shuffle_keys(uid, ep, self.n_t[r], self.nmax, self.seed)  # invalid positions sort last
         self.epoch[rows] += 1
-        invalid = torch.arange(self.nmax, device=self.device).unsqueeze(0) >= self.n_t[r].unsqueeze(1)
-        keys.masked_fill_(invalid, 2.0)
         self.perm[r] = keys.argsort(dim=1)
         self.cursor[rows] = 0
         self.cursor_t[r] = 0

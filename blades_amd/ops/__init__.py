@@ -191,6 +191,13 @@ def ce_topk(logits, labels, ks=(1,)):
     return ref.ce_topk(logits, labels, ks)
 
 
+def shuffle_keys(uids, epochs, lens, nmax, seed):
+    """Sort keys of the device batch sampler ``[rows, nmax]`` float64 (see reference.shuffle_keys)."""
+    if uids.is_cuda and not _FORCE_REFERENCE:
+        return _h().shuffle_keys(uids.contiguous(), epochs.contiguous(), lens.contiguous(), int(nmax), int(seed))
+    return ref.shuffle_keys(uids, epochs, lens, int(nmax), int(seed))
+
+
 def client_dropout_mult(uids, n, seed, tag, layer, p):
     """Client-keyed dropout multipliers ``[Kc, n]`` (see reference.client_dropout_mult)."""
     if uids.is_cuda and not _FORCE_REFERENCE and uids.dim() == 1 and torch.is_tensor(tag) and tag.is_cuda \

@@ -373,6 +373,20 @@ def client_dropout_mult(uids, n: int, seed: int, tag, layer: int, p: float):
     return out
 
 
+_shuffle_keys = _sig("blades_shuffle_keys", [_P, _P, _P, _P, c_int, c_int, c_ulonglong, _P])
+
+
+def shuffle_keys(uids, epochs, lens, nmax: int, seed: int):
+    """[rows, nmax] float64 sort keys of the batch sampler (see rng.hip shuffle_keys_kernel)."""
+    rows = uids.numel()
+    for t in (uids, epochs, lens):
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == rows):
+            raise ValueError("shuffle_keys: uids / epochs / lens must be contiguous CUDA int64 vectors of one length")
+    keys = _empty(rows, nmax, device=uids.device, dtype=torch.float64)
+    _shuffle_keys(_ptr(keys), _ptr(uids), _ptr(epochs), _ptr(lens), rows, nmax, seed & (2 ** 64 - 1), _stream())
+    return keys
+
+
 def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite):
     K, Dl, ld = _chk_matrix(U)
     rows = rows.to(dtype=torch.int64, device="cpu").reshape(-1, 2)
@@ -771,6 +785,68 @@ def ln_backward(x, gy, gamma, mean, rstd, Kc: int, coef, U_block, off_gamma: int
     if rc != 0:
         raise ValueError("ln_backward: unsupported shape")
     return dx
+
+
+# ---------------------------------------------------------------------------
+# fused small-sequence attention (ops/csrc/mha.hip)
+_mha_fwd = _sig("blades_mha_forward", [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_uint,
+                                       c_ulonglong, c_int, _P], c_int)
+_mha_bwd = _sig("blades_mha_backward", [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float,
+                                        c_uint, c_ulonglong, c_int, _P], c_int)
+
+
+def mha_supported(qkv: torch.Tensor) -> bool:
+    """qkv [R, N, 3, H, 64] (the fused projection's output), N <= 64."""
+    return (qkv.is_cuda and qkv.dtype in _ACT_DTYPES and qkv.dim() == 5 and qkv.shape[2] == 3 and qkv.shape[4] == 64
+            and 1 <= qkv.shape[1] <= 64 and qkv.shape[0] > 0)
+
+
+def _mha_drop(qkv, B, uids, tag, p):
+    R = qkv.shape[0]
+    if uids is None or p <= 0.0:
+        return None, None, 0.0
+    if not (uids.is_cuda and uids.dtype == torch.int64 and uids.is_contiguous() and R % B == 0
+            and uids.numel() == R // B):
+        raise ValueError("mha: uids must be a contiguous CUDA int64 vector with one entry per client")
+    if not (tag.is_cuda and tag.dtype == torch.int64 and tag.numel() == 1):
+        raise ValueError("mha: tag must be a 1-element CUDA int64 tensor")
+    return uids, tag, float(p)
+
+
+def mha_forward(qkv, B: int, scale: float, uids=None, tag=None, seed: int = 0, layer: int = 0, p: float = 0.0,
+                npl: int = 0):
+    """softmax(q k^T * scale) -> client-keyed dropout -> @ v for every (sample, head).  Returns
+    (o [R, N, H*64], lse [R, H, N])."""
+    if not mha_supported(qkv):
+        raise ValueError(f"mha_forward: unsupported input {qkv.dtype} {tuple(qkv.shape)}")
+    qkv = qkv.contiguous()
+    R, N, _, H, _ = qkv.shape
+    npl = 1 if qkv.dtype == torch.bfloat16 else (npl if npl in (2, 3) else 3)
+    uids, tag, p = _mha_drop(qkv, B, uids, tag, p)
+    o = _empty(R, N, H * 64, device=qkv.device, dtype=qkv.dtype)
+    lse = _empty(R, H, N, device=qkv.device, dtype=torch.float32)
+    rc = _mha_fwd(_ptr(qkv), _ptr(o), _ptr(lse), _ptr(uids), _ptr(tag), R, B if uids is not None else 1, N, H,
+                  float(scale), p, (2 + 256 * layer) & 0xFFFFFFFF, seed & (2 ** 64 - 1), npl, _stream())
+    if rc != 0:
+        raise ValueError("mha_forward: rejected")
+    return o, lse
+
+
+def mha_backward(qkv, o, d_o, lse, B: int, scale: float, uids=None, tag=None, seed: int = 0, layer: int = 0,
+                 p: float = 0.0, npl: int = 0):
+    qkv, o, d_o = qkv.contiguous(), o.contiguous(), d_o.contiguous()
+    R, N, _, H, _ = qkv.shape
+    if d_o.dtype != qkv.dtype or o.dtype != qkv.dtype or tuple(d_o.shape) != (R, N, H * 64) or o.shape != d_o.shape:
+        raise ValueError("mha_backward: d_o / o do not match qkv")
+    npl = 1 if qkv.dtype == torch.bfloat16 else (npl if npl in (2, 3) else 3)
+    uids, tag, p = _mha_drop(qkv, B, uids, tag, p)
+    dqkv = _empty_like(qkv)
+    rc = _mha_bwd(_ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(dqkv), _ptr(uids), _ptr(tag), R,
+                  B if uids is not None else 1, N, H, float(scale), p, (2 + 256 * layer) & 0xFFFFFFFF,
+                  seed & (2 ** 64 - 1), npl, _stream())
+    if rc != 0:
+        raise ValueError("mha_backward: rejected")
+    return dqkv
 
 
 # ---------------------------------------------------------------------------

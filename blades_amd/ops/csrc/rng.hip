@@ -71,7 +71,34 @@ __global__ __launch_bounds__(TPB) void client_dropout_kernel(float* __restrict__
     o[e] = u24(x) >= p ? keep_scale : 0.f;
   }
 }
+// Shuffle keys of the device batch sampler (engine/sampler.py): position `pos` of client `uid` in epoch `ep` gets the
+// 64-bit key (w0 : w1) of Philox counter (pos, uid, ep, 7), as a double in [-0.5, 0.5); positions past the client's shard
+// get 2.0 so they sort last.  One launch instead of the ~50 elementwise kernels of the torch formulation.
+__global__ __launch_bounds__(TPB) void shuffle_keys_kernel(double* __restrict__ keys, const long* __restrict__ uids,
+                                                           const long* __restrict__ epochs, const long* __restrict__ lens,
+                                                           int nmax, uint32_t k0, uint32_t k1) {
+  const int row = blockIdx.y;
+  const uint32_t uid = (uint32_t)uids[row], ep = (uint32_t)epochs[row];
+  const long len = lens[row];
+  for (int pos = blockIdx.x * TPB + threadIdx.x; pos < nmax; pos += gridDim.x * TPB) {
+    const Philox4 r = philox4x32_10((uint32_t)pos, uid, ep, 7u, k0, k1);
+    // the word pair read as a *signed* 64-bit integer, like the int64 arithmetic of the oracle: keys in [-0.5, 0.5)
+    const double key = (double)(long long)(((unsigned long long)r.x << 32) | r.y) * (1.0 / 18446744073709551616.0);
+    keys[(size_t)row * nmax + pos] = pos < len ? key : 2.0;
+  }
+}
 }  // namespace
+
+BLADES_API void blades_shuffle_keys(double* keys, const long* uids, const long* epochs, const long* lens, int rows,
+                                    int nmax, unsigned long long seed, hipStream_t st) {
+  if (rows <= 0 || nmax <= 0) return;
+  int g = cdiv(nmax, TPB); if (g > 64) g = 64;
+  for (int r0 = 0; r0 < rows; r0 += 65535) {
+    const int nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL(shuffle_keys_kernel, dim3(g, nr), dim3(TPB), 0, st, keys + (size_t)r0 * nmax, uids + r0,
+                       epochs + r0, lens + r0, nmax, (uint32_t)seed, (uint32_t)(seed >> 32));
+  }
+}
 
 BLADES_API void blades_client_dropout_mult(float* out, const long* uids, int Kc, long n, const long* tag, unsigned c3,
                                            unsigned long long seed, float p, hipStream_t st) {

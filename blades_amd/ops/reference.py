@@ -295,3 +295,29 @@ def ce_topk(logits: torch.Tensor, labels: torch.Tensor, ks=(1,)) -> torch.Tensor
     rank = ((lg > ly) | ((lg == ly) & (cls < y[:, None]))).sum(1)
     hits = [(rank < int(k)).sum().double() for k in ks]
     return torch.stack([ce] + hits)
+
+
+def mha(qkv, B: int, scale: float, uids=None, tag=0, seed: int = 0, layer: int = 0, p: float = 0.0):
+    """Oracle of ops/csrc/mha.hip: ``qkv [R, N, 3, H, hd]`` (client-major samples, ``B`` per client) ->
+    ``softmax(q k^T * scale)``, client-keyed dropout on the ``[B, H, N, N]`` probabilities of each client
+    (``client_dropout_mult``), ``@ v`` -> ``[R, N, H * hd]``.  Differentiable (plain torch ops)."""
+    R, N, _, H, hd = qkv.shape
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)  # [R, H, N, hd]
+    attn = ((q @ k.transpose(-2, -1)) * scale).softmax(dim=-1)
+    if uids is not None and p > 0.0:
+        m = client_dropout_mult(uids, B * H * N * N, seed, tag, layer, p)  # [Kc, B*H*N*N]
+        attn = attn * m.reshape(R, H, N, N).to(attn.dtype)
+    return (attn @ v).transpose(1, 2).reshape(R, N, H * hd)
+
+
+def shuffle_keys(uids, epochs, lens, nmax: int, seed: int):
+    """``[rows, nmax]`` float64 sort keys of the device batch sampler: position ``pos`` of client ``uid`` in epoch
+    ``ep`` -> the word pair of Philox counter ``(pos, uid, ep, 7)`` as a signed 64-bit integer / 2^64, in [-0.5, 0.5); positions past the
+    client's shard length get 2.0 (sort last)."""
+    rows = uids.numel()
+    pos = torch.arange(nmax, dtype=torch.int64, device=uids.device).unsqueeze(0).expand(rows, -1)
+    uid = uids.reshape(-1, 1).expand_as(pos)
+    ep = epochs.reshape(-1, 1).expand_as(pos)
+    w = _philox4x32(pos, uid & _MASK, ep & _MASK, torch.full_like(pos, 7), seed & _MASK, (seed >> 32) & _MASK)
+    keys = (w[0] * 4294967296 + w[1]).double() / float(2 ** 64)
+    return keys.masked_fill(pos >= lens.reshape(-1, 1), 2.0)
