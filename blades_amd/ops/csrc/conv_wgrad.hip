@@ -588,6 +588,332 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void conv_wgrad_kernel(const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Eight-wave variant for the fp32 planes (NPL = 2, 3), 3x3 stride-1 problems with power-of-two output geometry and an
+// arithmetic new-row schedule (every ResNet layer, and the parity classes of the strided ones).
+//
+// The plane images of a 64-channel tile fill LDS, so only one workgroup fits on a CU; with four waves that is one
+// wave per SIMD and nothing overlaps a wave's LDS fragment reads, plane splitting and staging stores with MFMA work
+// (PMC, profiles/r2_pmc_hot_kernels.txt: per K-step 3456 MFMA cycles, 2200 exposed read cycles, 1500 exposed
+// staging cycles).  Here the same tile is worked by eight waves — wave w owns input-channel block w & 3 and half
+// of the output-channel blocks (w >> 2) — so every SIMD holds two waves that hide each other's non-MFMA phases.
+// Waves 0-3 stage gy, waves 4-7 stage x: one 16-byte item (LPI loads) per thread and step.
+template <int TMT, int NPL, bool MASKED>
+__global__ __launch_bounds__(512, 1) void conv_wgrad8_kernel(const WgradParams p) {
+  static_assert(NPL >= 2 && TMT >= 2, "fp32 planes, at least two output-channel blocks");
+  constexpr int KS = 3, TAPS = 9, NPF = 3, LPI = 2, MH = TMT / 2;
+  using elem_t = float;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cib = wave & 3, half = wave >> 2;
+  const int per_xcd = gridDim.x >> 3;
+  const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (lid >= p.total_blocks) return;
+  const int n_ci_tiles = (p.Cin + 63) >> 6;
+  const int tile = lid % p.ntiles, rest = lid / p.ntiles;
+  const int c = rest % p.Kc, zsplit = rest / p.Kc;
+  const int n_cls_tiles = MASKED ? 4 * n_ci_tiles : n_ci_tiles;
+  const int co0 = (tile / n_cls_tiles) * (TMT * 16);
+  const int cls = MASKED ? (tile % n_cls_tiles) / n_ci_tiles : 0;
+  const int ci0 = ((tile % n_cls_tiles) % n_ci_tiles) * 64;
+  const int rp = cls >> 1, cp = cls & 1;
+  const int row_bits = rp ? 3 : 2, col_bits = cp ? 3 : 2;
+  int tap_mask = 0x1ff;
+  if constexpr (MASKED) {
+    tap_mask = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if ((row_bits >> r) & 1) tap_mask |= col_bits << (r * 3);
+  }
+  auto tap_dst = [&](int t) {
+    const int r = t / 3, sx = t - r * 3;
+    return (rp ? 2 * r : 1) * 3 + (cp ? 2 * sx : 1);
+  };
+  constexpr int GYM = 1024 + 32;
+  constexpr int GYB = TMT * GYM;
+  unsigned char* gy_lds = smem;
+  unsigned char* x_lds = smem + 2 * NPL * GYB;
+  const int plane_bytes = (p.nlines + 1) * p.wslots * 32 + 32;
+  const int xpl_bytes = 4 * plane_bytes;
+  const int line_mask = p.nlines - 1;
+  for (int i = tid * 16; i < NPL * xpl_bytes; i += 512 * 16) *reinterpret_cast<u32x4*>(x_lds + i) = u32x4{0, 0, 0, 0};
+
+  const elem_t* xc = reinterpret_cast<const elem_t*>(p.x) + (size_t)c * p.x_client_stride +
+                     (MASKED ? (size_t)(rp * (p.rmul >> 1) + cp) * p.Cin : (size_t)0);
+  const elem_t* gc = reinterpret_cast<const elem_t*>(p.gy) + (size_t)c * p.B * p.Ho * p.Wo * p.Cout;
+
+  // staging roles: waves 0-3 gy, waves 4-7 x; 8 lanes x 16 B (x LPI) cover one pixel's 64-channel tile
+  const bool is_x = tid >= 256;  // wave-uniform
+  const int chunk = tid & 7, pix = (tid >> 3) & 31;
+  const bool gy_lane = chunk < TMT * 2 && (co0 + chunk * 8) < p.Cout;
+  const bool x_lane = (ci0 + chunk * 8) < p.Cin;
+  struct Item { u32x4 v[LPI]; };
+  auto fetch = [&](const elem_t* src) {
+    Item it;
+#pragma unroll
+    for (int l = 0; l < LPI; ++l) it.v[l] = gload16_untracked(reinterpret_cast<const unsigned char*>(src) + 16 * l);
+    return it;
+  };
+  auto put = [&](unsigned char* dst, int plane_stride, const Item& it) {
+    u32x4 pl[NPL];
+    split8<NPL>(it.v[0], it.v[1], pl);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(dst + q * plane_stride) = pl[q];
+  };
+  const __attribute__((address_space(4))) int* tbl = (const __attribute__((address_space(4))) int*)(p.table);
+  const elem_t* zeros16 = reinterpret_cast<const elem_t*>(p.table + (size_t)p.nsteps * TBL);
+  // new input rows of step s > its block's first: (s R + off, (s + 1) R + off], clipped to the client's last row
+  auto row_hi = [&](int s) { const int v = (s + 1) * p.rows_r + p.rows_off; return v < p.rows_last ? v : p.rows_last; };
+  auto row_lo = [&](int s) { const int v = s * p.rows_r + p.rows_off; return (v < p.rows_last ? v : p.rows_last) + 1; };
+  auto issue = [&](int s) {
+    const elem_t* a = zeros16;
+    if (!is_x) {
+      const int gpix = s * 32 + pix;
+      if (gy_lane && gpix < p.nquads * 4) a = gc + (size_t)gpix * p.Cout + co0 + chunk * 8;
+    } else {
+      const int lo = row_lo(s), npix = (row_hi(s) - lo + 1) * p.W;
+      if (x_lane && pix < npix) {
+        const int er = pix >> p.w_shift;
+        const size_t pixel = (size_t)(lo + er) * p.rmul + (size_t)(pix - er * p.W) * p.cmul;
+        a = xc + pixel * p.Cin + ci0 + chunk * 8;
+      }
+    }
+    return fetch(a);
+  };
+  auto commit = [&](int s, const Item& it) {
+    if (!is_x) {
+      if (chunk < TMT * 2)
+        put(gy_lds + (s & 1) * NPL * GYB + (chunk >> 1) * GYM + pix * 32 + (chunk & 1) * 16, GYB, it);
+    } else {
+      const int lo = row_lo(s), npix = (row_hi(s) - lo + 1) * p.W;
+      if (pix < npix) {
+        const int er = pix >> p.w_shift;
+        const int row = lo + er, iw = pix - er * p.W + p.pad;
+        put(x_lds + (chunk >> 1) * plane_bytes + ((row & line_mask) * p.wslots + iw) * 32 + (chunk & 1) * 16,
+            xpl_bytes, it);
+      }
+    }
+  };
+
+  f32x4 acc[MH][TAPS];
+#pragma unroll
+  for (int m = 0; m < MH; ++m)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool wave_active = (ci0 + cib * 16) < p.Cin;
+  const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+  const unsigned char* x_plane = x_lds + cib * plane_bytes + lq * 32 + lp * 8;
+  const int per = (p.nsteps + p.split - 1) / p.split;
+  const int blk_begin = zsplit * per;
+  const int blk_end = blk_begin + per < p.nsteps ? blk_begin + per : p.nsteps;
+  int s_begin = 0, s_end = 0;
+  __syncthreads();  // zero fill done
+
+  Item stg[NPF];
+  auto compute = [&](int s) {
+    if (wave_active) {
+      int gi0[2], ih0[2], ow0[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int Q = s * 8 + 4 * t + g;
+        const int qx = Q & ((1 << p.lg_qpr) - 1);
+        const int oh = (Q >> p.lg_qpr) & ((1 << p.lg_ho) - 1);
+        const int b = Q >> (p.lg_qpr + p.lg_ho);
+        ow0[t] = qx * 4;
+        ih0[t] = Q < p.nquads ? oh - p.pad : -1000000;
+        gi0[t] = b * p.H + oh - p.pad;
+      }
+      const unsigned char* gy_buf = gy_lds + (s & 1) * NPL * GYB + lq * 32 + lp * 8;
+      const unsigned char* bp[KS][2];
+#pragma unroll
+      for (int r = 0; r < KS; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ih = ih0[t] + r;
+          const int line = ((unsigned)ih < (unsigned)p.H) ? ((gi0[t] + r) & line_mask) : p.nlines;
+          bp[r][t] = x_plane + (line * p.wslots + ow0[t]) * 32;
+        }
+      i32x2 hb[2][NPL][KS * 2];
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) hb[0][q][sx * 2 + t] = tr_read(bp[0][t] + q * xpl_bytes + sx * 32);
+      i32x4 a[NPL][MH];
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int m = 0; m < MH; ++m) {
+          const unsigned char* gb = gy_buf + q * GYB + (half * MH + m) * GYM;
+          const i32x2 lo = tr_read(gb + (0 * 16 + g * 4) * 32), hi = tr_read(gb + (1 * 16 + g * 4) * 32);
+          a[q][m] = i32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+      for (int r = 0; r < KS; ++r) {
+        if (r + 1 < KS && (!MASKED || ((tap_mask >> ((r + 1) * KS)) & 7))) {
+#pragma unroll
+          for (int q = 0; q < NPL; ++q)
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+                hb[(r + 1) & 1][q][sx * 2 + t] = tr_read(bp[r + 1][t] + q * xpl_bytes + sx * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sx = 0; sx < KS; ++sx) {
+          if (MASKED && !((tap_mask >> (r * KS + sx)) & 1)) continue;  // block-uniform
+          bf16x8 b[NPL];
+#pragma unroll
+          for (int q = 0; q < NPL; ++q) {
+            const i32x2 h0 = hb[r & 1][q][sx * 2 + 0], h1 = hb[r & 1][q][sx * 2 + 1];
+            b[q] = __builtin_bit_cast(bf16x8, i32x4{h0[0], h0[1], h1[0], h1[1]});
+          }
+#pragma unroll
+          for (int m = 0; m < MH; ++m) {
+            f32x4 d = acc[m][r * KS + sx];
+            if constexpr (NPL == 3) {
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1][m]), b[1], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]), b[2], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[2][m]), b[0], d, 0, 0, 0);
+            }
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]), b[1], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1][m]), b[0], d, 0, 0, 0);
+            acc[m][r * KS + sx] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]), b[0], d, 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  auto step = [&](int s, Item& slot_far, const Item& slot_next) {
+    if (s + NPF < s_end) slot_far = issue(s + NPF);
+    compute(s);
+    if (s + 1 < s_end) {
+      if (s + NPF < s_end) wait_vmcnt<(NPF - 1) * LPI>();
+      else wait_vmcnt<0>();
+      commit(s + 1, slot_next);
+    }
+    __syncthreads();
+  };
+
+  const int nblk_steps = blk_end - blk_begin;
+  const int rot = nblk_steps > 1 ? (int)(((unsigned)c * 7919u + (unsigned)zsplit * 104729u) % (unsigned)nblk_steps) : 0;
+  for (int seg = 0; seg < 2; ++seg) {
+    s_begin = seg == 0 ? blk_begin + rot : blk_begin;
+    s_end = seg == 0 ? blk_end : blk_begin + rot;
+    if (s_begin >= s_end) continue;
+    {
+      // prologue: the whole row window of the first step and its gy tile, synchronously (all 512 threads load x)
+      const __attribute__((address_space(4))) int* T = tbl + (size_t)s_begin * TBL;
+      const int w_lo = T[34], w_hi = T[33];
+      const int npix = (w_hi - w_lo + 1) * p.W;
+      for (int e = tid >> 3; e < npix; e += 64) {
+        if (x_lane) {
+          const int er = e >> p.w_shift;
+          const size_t pixel = (size_t)(w_lo + er) * p.rmul + (size_t)(e - er * p.W) * p.cmul;
+          const elem_t* src = xc + pixel * p.Cin + ci0 + chunk * 8;
+          Item it;
+#pragma unroll
+          for (int l = 0; l < LPI; ++l)
+            it.v[l] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) + 16 * l);
+          const int row = w_lo + er, iw = e - er * p.W + p.pad;
+          put(x_lds + (chunk >> 1) * plane_bytes + ((row & line_mask) * p.wslots + iw) * 32 + (chunk & 1) * 16,
+              xpl_bytes, it);
+        }
+      }
+      if (!is_x) {
+        Item it;
+#pragma unroll
+        for (int l = 0; l < LPI; ++l) it.v[l] = u32x4{0, 0, 0, 0};
+        const int gpix = s_begin * 32 + pix;
+        if (gy_lane && gpix < p.nquads * 4) {
+          const elem_t* src = gc + (size_t)gpix * p.Cout + co0 + chunk * 8;
+#pragma unroll
+          for (int l = 0; l < LPI; ++l)
+            it.v[l] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) + 16 * l);
+        }
+        if (chunk < TMT * 2)
+          put(gy_lds + (s_begin & 1) * NPL * GYB + (chunk >> 1) * GYM + pix * 32 + (chunk & 1) * 16, GYB, it);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < NPF; ++k)
+      if (s_begin + k < s_end) stg[k] = issue(s_begin + k);
+    for (int s0 = s_begin; s0 < s_end; s0 += NPF) {
+#pragma unroll
+      for (int k = 0; k < NPF; ++k)
+        if (s0 + k < s_end) step(s0 + k, stg[k], stg[(k + 1) % NPF]);
+    }
+  }
+
+  // ---- epilogue: each wave's [MH x 16 co][16 ci x 9 taps] through LDS, lane-contiguous stores ------------------
+  const bool to_scratch = p.split > 1;
+  const float cf = (p.coef && !to_scratch) ? p.coef[c] : 1.f;
+  float* row = to_scratch ? p.scratch + ((size_t)zsplit * p.Kc + c) * p.numel : p.U + (size_t)c * p.ld + p.off;
+  const bool accum = p.accumulate && !to_scratch;
+  constexpr int SEG = 16 * TAPS, SEGP = SEG + 4;
+  const bool full_tile = (p.Cs == p.Cin) && (ci0 + 64 <= p.Cin);  // block-uniform
+  if (full_tile) {
+    float* tile_l = reinterpret_cast<float*>(smem) + wave * 16 * SEGP;
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+      __syncthreads();
+      if constexpr (MASKED) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t)
+            if ((tap_mask >> t) & 1) tile_l[(g * 4 + q) * SEGP + li * TAPS + tap_dst(t)] = cf * acc[m][t][q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) tile_l[(g * 4 + q) * SEGP + li * TAPS + t] = cf * acc[m][t][q];
+      }
+      __syncthreads();
+      float* dst0 = row + ((size_t)(co0 + (half * MH + m) * 16) * p.Cin + ci0 + cib * 16) * TAPS;
+#pragma unroll
+      for (int j = 0; j < 16 * SEG / 64; ++j) {
+        const int f = j * 64 + lane;
+        const int r = f / SEG, col = f - r * SEG;
+        float* d = dst0 + (size_t)r * p.Cin * TAPS + col;
+        const float v = tile_l[r * SEGP + col];
+        if constexpr (MASKED) {
+          const int k = col % TAPS, kr = k / 3, kc = k - kr * 3;
+          if ((kr == 1) == (rp == 0) && (kc == 1) == (cp == 0)) *d = accum ? *d + v : v;
+        } else {
+          *d = accum ? *d + v : v;
+        }
+      }
+    }
+    return;
+  }
+  if (wave_active) {
+    const int ci = ci0 + cib * 16 + li;
+#pragma unroll
+    for (int m = 0; m < MH; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = co0 + (half * MH + m) * 16 + g * 4 + q;
+        if (co < p.Cout && ci < p.Cs) {
+          float* dst = row + ((size_t)co * p.Cs + ci) * TAPS;
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t)
+            if (!MASKED || ((tap_mask >> t) & 1)) {
+              const float v = cf * acc[m][t][q];
+              float* d = dst + (MASKED ? tap_dst(t) : t);
+              *d = accum ? *d + v : v;
+            }
+        }
+      }
+  }
+}
+
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ scratch, int split, int Kc,
                                                            long numel, const float* __restrict__ coef,
                                                            float* __restrict__ U, long ld, long off, int accumulate) {
@@ -619,6 +945,33 @@ int launch(const WgradParams& p, int Kc, hipStream_t st) {
   q.total_blocks = q.ntiles * Kc * p.split;
   const int grid = (q.total_blocks + 7) / 8 * 8;
   hipLaunchKernelGGL((conv_wgrad_kernel<TMT, KS, MAXP, NPF, FAST, NPL, MASKED>), dim3(grid), dim3(256), lds, st, q);
+  if (p.split > 1) {
+    int gx = cdiv(p.numel, 256 * 4);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, Kc), dim3(256), 0, st, p.scratch, p.split, Kc, p.numel, p.coef,
+                       p.U, p.ld, p.off, p.accumulate);
+  }
+  return 0;
+}
+
+template <int TMT, int NPL, bool MASKED>
+int launch8(const WgradParams& p, int Kc, hipStream_t st) {
+  size_t lds = NPL * (2 * TMT * (1024 + 32) + 4 * ((size_t)(p.nlines + 1) * p.wslots * 32 + 32));
+  const size_t lds_epilogue = 8 * 16 * (16 * 9 + 4) * sizeof(float);
+  if (lds < lds_epilogue) lds = lds_epilogue;
+  if (lds > 160 * 1024) return 3;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad8_kernel<TMT, NPL, MASKED>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int n_ci_tiles = (p.Cin + 63) / 64, n_co_tiles = p.Cout / (TMT * 16);
+  WgradParams q = p;
+  q.ntiles = n_co_tiles * n_ci_tiles * (MASKED ? 4 : 1);
+  q.total_blocks = q.ntiles * Kc * p.split;
+  const int grid = (q.total_blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL((conv_wgrad8_kernel<TMT, NPL, MASKED>), dim3(grid), dim3(512), lds, st, q);
   if (p.split > 1) {
     int gx = cdiv(p.numel, 256 * 4);
     if (gx > 1024) gx = 1024;
@@ -685,6 +1038,20 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
     if (npl == 2) return fast ? launch<T, 3, 1, 3, true, 2, true>(p, Kc, st) : launch<T, 3, 1, 2, false, 2, true>(p, Kc, st); \
     return fast ? launch<T, 3, 1, 3, true, 3, true>(p, Kc, st) : launch<T, 3, 1, 2, false, 3, true>(p, Kc, st);               \
   } while (0)
+  // fp32 planes on the regular ResNet geometry: the eight-wave kernel (BLADES_WGRAD_WAVES=4 keeps the four-wave one)
+  static const bool waves8 = []() { const char* e = getenv("BLADES_WGRAD_WAVES"); return !(e && atoi(e) == 4); }();
+  if (waves8 && npl >= 2 && ks == 3 && stride == 1 && fast && passes <= 1 && rows_r > 0 && p.w_shift >= 0 &&
+      tmt >= 2 && !p.ablate) {
+#define GO8(T, M)                                              \
+  do {                                                         \
+    if (npl == 2) return launch8<T, 2, M>(p, Kc, st);          \
+    return launch8<T, 3, M>(p, Kc, st);                        \
+  } while (0)
+    if (masked) { if (tmt == 4) GO8(4, true); GO8(2, true); }
+    if (tmt == 4) GO8(4, false);
+    GO8(2, false);
+#undef GO8
+  }
   if (masked) { if (tmt == 4) GOM(4); if (tmt == 2) GOM(2); GOM(1); }
 #undef GOM
   if (ks == 3) { if (tmt == 4) GO(4, 3); if (tmt == 2) GO(2, 3); if (tmt == 1) GO(1, 3); }
