@@ -180,7 +180,9 @@ def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, over
 
 
 def power_iteration_top(G, iters=8):
-    # K x K linear algebra (K = clients): library GEMMs on either device.
+    """Top eigenvector of the K x K Gram matrix (DnC's outlier direction).  Deliberately NOT a hand-written kernel:
+    K is the number of clients (<= a few thousand), so this is ``iters`` K x K matrix-vector products — microseconds of
+    library GEMV on either device (DnC at K = 1000: 8 x 1 M-element products), and it stays on the device (no sync)."""
     return ref.power_iteration_top(G, iters)
 
 
