@@ -80,6 +80,11 @@ class ClientEngine:
             # proportionally fewer clients so that activation memory stays put.  CPU runs keep chunks small.
             on_gpu = self.device.type == "cuda"
             clients_per_chunk = max(8, min(200, (200 * 64) // max(int(batch_size), 1))) if on_gpu else 64
+            # fp32 planes on a large convolutional model: the MFMA-bound kernels are full at 40 x 64 samples and the
+            # smaller working set is worth 5 % (profiles/r2_chunk_stream_sweep_fp32.txt)
+            n_par = sum(p.numel() for p in task.model.parameters())
+            if on_gpu and amp_dtype in ("auto", "fp32", "bf16x3", None) and n_par > 8_000_000:
+                clients_per_chunk = max(8, clients_per_chunk // 5)
         self.chunk = max(1, int(clients_per_chunk))
         self.eval_chunk = eval_clients_per_chunk or self.chunk
         self.num_classes = num_classes

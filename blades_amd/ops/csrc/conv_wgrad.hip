@@ -788,10 +788,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad8_kernel(const WgradParams p
       }
     }
   };
+  const bool ab_stage = (p.ablate & 1) != 0, ab_mfma = (p.ablate & 2) != 0;  // diagnostics (BLADES_WGRAD_ABLATE)
   auto step = [&](int s, Item& slot_far, const Item& slot_next) {
-    if (s + NPF < s_end) slot_far = issue(s + NPF);
-    compute(s);
-    if (s + 1 < s_end) {
+    if (s + NPF < s_end && !ab_stage) slot_far = issue(s + NPF);
+    if (!ab_mfma) compute(s);
+    if (s + 1 < s_end && !ab_stage) {
       if (s + NPF < s_end) wait_vmcnt<(NPF - 1) * LPI>();
       else wait_vmcnt<0>();
       commit(s + 1, slot_next);
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad8_kernel(const WgradParams p
     __syncthreads();
 #pragma unroll
     for (int k = 1; k < NPF; ++k)
-      if (s_begin + k < s_end) stg[k] = issue(s_begin + k);
+      if (s_begin + k < s_end && !ab_stage) stg[k] = issue(s_begin + k);
     for (int s0 = s_begin; s0 < s_end; s0 += NPF) {
 #pragma unroll
       for (int k = 0; k < NPF; ++k)
@@ -1041,7 +1042,7 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
   // fp32 planes on the regular ResNet geometry: the eight-wave kernel (BLADES_WGRAD_WAVES=4 keeps the four-wave one)
   static const bool waves8 = []() { const char* e = getenv("BLADES_WGRAD_WAVES"); return !(e && atoi(e) == 4); }();
   if (waves8 && npl >= 2 && ks == 3 && stride == 1 && fast && passes <= 1 && rows_r > 0 && p.w_shift >= 0 &&
-      tmt >= 2 && !p.ablate) {
+      tmt >= 2) {
 #define GO8(T, M)                                              \
   do {                                                         \
     if (npl == 2) return launch8<T, 2, M>(p, Kc, st);          \
