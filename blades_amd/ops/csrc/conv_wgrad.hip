@@ -118,17 +118,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NPL: operand planes.  1 = bf16 activations as they are.  2 / 3 = fp32 activations, split exactly into bf16 planes
 // (x = h + m (+ l)) when a staged tile is committed to LDS; every plane pair that matters is multiplied
 // (NPL = 3: hh + hm + mh + hl + lh + mm, fp32 grade; NPL = 2: hh + hm + mh) into the same fp32 accumulators.
+// x = h + m (+ l) with bf16 planes, exact.  One v_cvt_pk_bf16_f32 per *pair* of values and plane: the packed result
+// is both the plane's output dword and, shifted / masked back into fp32 position, the value to subtract for the next
+// plane (the vector-convert formulation costs three conversions per pair).
 template <int NPL>
 __device__ __forceinline__ void split8(const u32x4 lo, const u32x4 hi, u32x4 (&pl)[NPL]) {
-  typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-  typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
-  f32x4 r0 = __builtin_bit_cast(f32x4, lo), r1 = __builtin_bit_cast(f32x4, hi);
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r[j] = __uint_as_float(lo[j]); r[4 + j] = __uint_as_float(hi[j]); }
 #pragma unroll
   for (int q = 0; q < NPL; ++q) {
-    const bf16x4v b0 = __builtin_convertvector(r0, bf16x4v), b1 = __builtin_convertvector(r1, bf16x4v);
-    const u32x2v u0 = __builtin_bit_cast(u32x2v, b0), u1 = __builtin_bit_cast(u32x2v, b1);
-    pl[q] = u32x4{u0[0], u0[1], u1[0], u1[1]};
-    if (q + 1 < NPL) { r0 -= __builtin_convertvector(b0, f32x4); r1 -= __builtin_convertvector(b1, f32x4); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v{r[2 * j], r[2 * j + 1]}), bf16x2v));
+      pl[q][j] = u;
+      if (q + 1 < NPL) {
+        r[2 * j] -= __uint_as_float(u << 16);
+        r[2 * j + 1] -= __uint_as_float(u & 0xffff0000u);
+      }
+    }
   }
 }
 
@@ -710,8 +720,12 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad8_kernel(const WgradParams p
   __syncthreads();  // zero fill done
 
   Item stg[NPF];
-  auto compute = [&](int s) {
-    if (wave_active) {
+  // `mid(r)` runs after the MFMAs of kernel row r have been issued: the staging commit of the next step goes there
+  // (row 0 for one wave group, row 1 for the other), so on every SIMD one wave converts / stores while the other
+  // keeps the matrix pipe busy — at the end of the step both would do it at the same time with the pipe idle.
+  auto compute = [&](int s, auto&& mid) {
+    if (!wave_active) { mid(0); mid(1); return; }
+    {
       int gi0[2], ih0[2], ow0[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -785,18 +799,25 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad8_kernel(const WgradParams p
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (r < 2) mid(r);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
+  const int grp = __builtin_amdgcn_readfirstlane(half);
   const bool ab_stage = (p.ablate & 1) != 0, ab_mfma = (p.ablate & 2) != 0;  // diagnostics (BLADES_WGRAD_ABLATE)
   auto step = [&](int s, Item& slot_far, const Item& slot_next) {
     if (s + NPF < s_end && !ab_stage) slot_far = issue(s + NPF);
-    if (!ab_mfma) compute(s);
-    if (s + 1 < s_end && !ab_stage) {
-      if (s + NPF < s_end) wait_vmcnt<(NPF - 1) * LPI>();
-      else wait_vmcnt<0>();
-      commit(s + 1, slot_next);
-    }
+    auto stage_next = [&](int r) {
+      if (r != grp || s + 1 >= s_end || ab_stage) return;
+      if (!(p.ablate & 4)) {
+        if (s + NPF < s_end) wait_vmcnt<(NPF - 1) * LPI>();
+        else wait_vmcnt<0>();
+      }
+      if (!(p.ablate & 8)) commit(s + 1, slot_next);
+    };
+    if (!ab_mfma) compute(s, stage_next);
+    else { stage_next(0); stage_next(1); }
     __syncthreads();
   };
 
