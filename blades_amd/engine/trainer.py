@@ -486,7 +486,106 @@ class ClientEngine:
                 self.U_row[rows_t, : self.D] = G
         return losses
 
+    def _general_graphs_wanted(self) -> bool:
+        if self.hip_graphs in ("0", "off", "false") or self._graph_failed:
+            return False
+        if self.device.type != "cuda" or not self.fused_pc or self.nb <= 1:
+            return False
+        if self.hip_graphs in ("1", "on", "true"):
+            return True
+        return len(self._train_rows) * self.B * self.D <= 5e10  # launch-bound rounds only, as for FedSGD chunks
+
+    def _graphed_local_steps(self, theta, rows, srows):
+        """Several local steps per round on launch-bound models: ONE local step of the chunk (batch gather,
+        augmentation, per-client-weight forward / backward on the fused executor, client SGD step) is captured as a
+        HIP graph on persistent per-chunk weight / gradient / momentum buffers and replayed ``nb`` times per round;
+        the host only advances the sampler bookkeeping, the dropout tag and the augmentation table in between.
+        Returns the mean losses, or ``None`` when the chunk is not graphable (the eager loop runs instead)."""
+        tf = self.dataset.train_transform
+        aug = tf is not None and hasattr(tf, "draw")
+        if tf is not None and not aug:
+            return None
+        gscale0, flip, gclip = self._row_vectors(rows)
+        if self._any_clip:
+            return None
+        key = (b"g", rows.tobytes(), srows.tobytes(), self._spec_version)
+        ent = self._chunk_graphs.get(key)
+        if ent is None:
+            if len(self._chunk_graphs) > 64:
+                self._chunk_graphs.clear()
+            ent = self._chunk_graphs[key] = {"visits": 0, "graph": None}
+        ent["visits"] += 1
+        if ent["graph"] is None and ent["visits"] <= 2:
+            return None  # eager first (plan tables, first-use allocations, momentum initialisation)
+        Kc = len(rows)
+        srows_t = torch.as_tensor(srows, device=self.device)
+        rows_t = torch.as_tensor(rows, device=self.device)
+        if ent["graph"] is None:
+            any_flip = self._any_flip
+            dev_rows = self.sampler.rows_on_device(srows)
+            store = self.train_store
+            W = torch.empty(Kc, self.D, device=self.device)
+            G = torch.empty_like(W)
+            Mv = torch.zeros_like(W) if self.momentum != 0.0 else W
+            loss_acc = torch.zeros(Kc, device=self.device)
+            params = torch.zeros(Kc, 9, device=self.device) if aug else None
+            uids_t = self._chunk_uids(srows)
+            W.copy_(theta.unsqueeze(0).expand(Kc, -1))  # valid weights while capturing
+
+            def body():
+                self.drop_ctx.set(uids_t, "major")
+                idx = self.sampler.gather_indices(dev_rows).reshape(-1)
+                X = store.x[idx].reshape(Kc, self.B, *store.x.shape[1:])
+                Y = store.y[idx].reshape(Kc, self.B)
+                if aug:
+                    X = tf.apply(X, params)
+                if any_flip:
+                    Y = torch.where(flip.unsqueeze(1) > 0, flip.unsqueeze(1) - 1 - Y, Y)
+                losses = self.fused.run_per_client(W, X, Y, G)
+                ops.client_sgd_step_(W, G, Mv, self.lr, self.momentum, False, gscale0)
+                loss_acc.add_(losses)
+
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    body()
+            except Exception as e:  # noqa: BLE001 — not capturable: eager for good
+                self._graph_failed = True
+                self._graph_error = repr(e)
+                self._chunk_graphs.clear()
+                torch.cuda.synchronize()
+                return None
+            ent.update(graph=g, W=W, G=G, Mv=Mv, loss=loss_acc, params=params,
+                       keep=(flip, gscale0, dev_rows, uids_t))
+        W, Mv, loss_acc = ent["W"], ent["Mv"], ent["loss"]
+        W.copy_(theta.unsqueeze(0).expand(Kc, -1))
+        loss_acc.zero_()
+        if self.momentum != 0.0:
+            if self.M is None:
+                self.M = torch.zeros(len(self._train_rows), self.D, device=self.device)
+            Mv.copy_(self.M[srows_t])
+        hw = store_hw(self.train_store)
+        for step in range(self.nb):
+            self._local_step = step
+            self.sampler.prepare(srows)
+            self.drop_ctx.set_tag(self._drop_tag())
+            if aug:
+                table = tf.draw(Kc, None, hw[0], hw[1], uniforms=self._aug_uniforms(srows, tf))
+                tf.check(table, *hw)
+                ent["params"].copy_(table)
+            ent["graph"].replay()
+            self.graph_replays += 1
+            self.sampler.finish(srows)
+        if self.momentum != 0.0:
+            self.M[srows_t] = Mv
+        self.U_row[rows_t, : self.D] = W - theta.unsqueeze(0)
+        return loss_acc / self.nb
+
     def _train_chunk_general(self, theta, rows, srows):
+        if self._general_graphs_wanted() and self._mom_init:
+            losses = self._graphed_local_steps(theta, rows, srows)
+            if losses is not None:
+                return losses
         gscale0, flip, gclip = self._row_vectors(rows)
         Kc = len(rows)
         W = theta.unsqueeze(0).repeat(Kc, 1)  # a real copy even for Kc == 1 (expand().contiguous() would alias theta)

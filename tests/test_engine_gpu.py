@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2, server_lr=0.0, chunk="auto"):
+def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2, server_lr=0.0, chunk="auto", nb=1, momentum=0.0, lr=1.0):
     from blades_amd.algorithms.fedavg import FedavgConfig
 
     old = os.environ.get("BLADES_HIP_GRAPH")
@@ -21,7 +21,7 @@ def _run(tmp_path, mode, ds, model, adv, rounds=6, K=8, f=2, server_lr=0.0, chun
                                      "use_cache": False})
                .training(global_model=model, server_config={"aggregator": {"type": "Median"},
                                                             "optimizer": {"lr": server_lr, "momentum": 0.0}})
-               .client(client_config={"lr": 1.0})
+               .client(client_config={"lr": lr, "momentum": momentum, "num_batch_per_round": nb})
                .adversary(num_malicious_clients=f, adversary_config={"type": f"blades.adversaries.{adv}"})
                .evaluation(evaluation_interval=0)
                .engine(clients_per_chunk=chunk))
@@ -67,6 +67,29 @@ def test_graph_replay_matches_eager_bitwise(tmp_path, ds, model, adv, chunk):
     else:
         # Dropout2d: the graph-safe RNG stream differs from the eager one, so only the statistics agree
         assert max(abs(a - b) for a, b in zip(loss_g, loss_e)) < 0.3, (loss_g, loss_e)
+
+
+@pytest.mark.parametrize("ds,model,momentum,chunk", [("mnist", "mlp", 0.9, "auto"), ("cifar10", "resnet", 0.0, 3),
+                                                     ("cifar10", "resnet", 0.9, "auto")])
+def test_graphed_local_steps_match_eager(tmp_path, ds, model, momentum, chunk):
+    """Several local steps per round: one local step captured as a HIP graph on persistent per-chunk weight /
+    gradient / momentum buffers and replayed nb times must reproduce the eager loop (same batches, same
+    client-keyed dropout masks, same augmentation), bit for bit on the framework's own kernels."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    kw = dict(rounds=6, nb=3, momentum=momentum, lr=0.05, chunk=chunk)
+    th_e, loss_e, eng_e = _run(tmp_path, "0", ds, model, "ALIEAdversary", **kw)
+    th_g, loss_g, eng_g = _run(tmp_path, "1", ds, model, "ALIEAdversary", **kw)
+    assert eng_e.graph_replays == 0
+    # round 1 initialises the momentum, rounds 2-3 run eager (first-use allocations), rounds 4-6 replay
+    assert eng_g.fused_pc and eng_g.graph_replays >= 3 * 3, (getattr(eng_g, "_graph_error", None), eng_g.graph_replays)
+    assert all(l == l for l in loss_g) and torch.isfinite(th_g).all()
+    if model == "mlp":  # Linear layers go through hipBLASLt: equal up to its run-to-run solver choice
+        assert max(abs(a - b) for a, b in zip(loss_g, loss_e)) < 1e-4, (loss_g, loss_e)
+        torch.testing.assert_close(th_g, th_e, rtol=1e-3, atol=1e-6)
+    else:
+        assert loss_g == loss_e
+        assert torch.equal(th_g, th_e)
 
 
 def test_auto_mode_picks_graphs_only_for_small_rounds(tmp_path):
