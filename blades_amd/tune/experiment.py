@@ -245,6 +245,10 @@ class TrialScheduler:
                     cmd = [sys.executable, "-m", "blades_amd.tune.trial_worker", spec.name]
                 running.append((self._popen(cmd, env=env), token, trial, spec.name))
                 self.max_in_flight = max(self.max_in_flight, len(running))
+                if verbose:
+                    share = ", ".join(f"GPU {g} x{sh:g}" for g, sh in token) if self.num_gpus else "CPU"
+                    print(f"[tune {time.strftime('%H:%M:%S')}] started {trial.get('dir_name', '?')} on {share} "
+                          f"({len(running)} in flight)", flush=True)
             still = []
             for proc, gpus, trial, specfile in running:
                 rc = proc.poll()
@@ -254,6 +258,9 @@ class TrialScheduler:
                     rcs.append(rc)
                     slots.release(gpus)
                     os.unlink(specfile)
+                    if verbose:
+                        print(f"[tune {time.strftime('%H:%M:%S')}] finished {trial.get('dir_name', '?')} (exit {rc})",
+                              flush=True)
                     if rc != 0:
                         print(f"[tune] trial {trial['dir_name']} failed with exit code {rc}", file=sys.stderr)
             running = still

@@ -1,7 +1,7 @@
 """Timing of conv_igemm on chosen layers: python tools/probes/conv_igemm_time.py --npl 3 --n 12800 [--layers 0 1]"""
 import argparse, sys, time
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from blades_amd.ops import _hip as h
 
 LAYERS = [(64, 32, 64, 3, 1, 1), (128, 16, 128, 3, 1, 1), (256, 8, 256, 3, 1, 1), (512, 4, 512, 3, 1, 1),
