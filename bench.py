@@ -134,7 +134,7 @@ def main():
         tw = time.perf_counter()
         algo.train()
         sync()
-        note(f"warmup round {i} (includes MIOpen kernel search): {time.perf_counter() - tw:.1f}s")
+        note(f"warmup round {i} (first-use allocations, kernel plan tables): {time.perf_counter() - tw:.1f}s")
     sync()
     warming.clear()
     algo._timers.reset()  # phase means below cover the timed rounds only

@@ -71,6 +71,9 @@ struct IgemmParams {
   int n_clients, imgs_per_client;  // per-client weights (local steps > 1): image n uses weight set n / imgs_per_client
   long wp_client_stride, bias_client_stride;  // elements between two clients' weight planes / biases
   int ablate;                 // diagnostics (BLADES_IGEMM_ABLATE): 1 no staging loads, 2 no commit, 4 no MFMAs
+  int Hphys, Wphys, in_rm, in_cm;  // the input may be a strided view in[:, ::rm, ::cm] of a [Hphys][Wphys] image (a
+                                   // strided 1x1 convolution only ever touches those pixels: it runs as a stride-1
+                                   // convolution on the view, staging a quarter of the pixels)
 };
 
 // exact for 0 <= e < 2^20, 1 <= d < 2^12: (e + 0.5) / d is at least 0.5/d away from any integer
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     const int iy = iy_lo + r;
     const bool ok = e < p.region_px && (unsigned)iy < (unsigned)p.Hi && img0 + il < p.N;
     d.slot = il * p.IS + r * p.WS + ix + p.PL;
-    d.goff = ok ? (((long)(img0 + il) * p.Hi + iy) * p.Wi + ix) * p.Ci : -1;
+    d.goff = ok ? (((long)(img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci : -1;
     return d;
   };
   const bool vec_in = (p.Ci % CPL) == 0;
@@ -503,15 +506,21 @@ BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bi
   p.n_clients = n_clients; p.imgs_per_client = N / n_clients;
   p.wp_client_stride = (long)npl * taps * rows_pad * k_pad; p.bias_client_stride = bias_client_stride;
   int ay[MAXTAPS], ax[MAXTAPS];
+  p.in_rm = p.in_cm = 1;
   if (mode == 0) {
     p.Hi = H; p.Wi = W; p.Ci = Ci; p.Hout = Ho; p.Wout = Wo; p.Co = Co;
     p.Hs = Ho; p.Ws = Wo; p.so = 1; p.poy = 0; p.pox = 0; p.si = stride;
+    p.Hphys = H; p.Wphys = W;
+    if (taps == 1 && pad == 0 && stride > 1) {  // strided 1x1: stride-1 on the view in[:, ::stride, ::stride]
+      p.Hi = Ho; p.Wi = Wo; p.si = 1; p.in_rm = p.in_cm = stride;
+    }
     p.ntaps = taps;
     for (int r = 0; r < kh; ++r)
       for (int s = 0; s < kw; ++s) { ay[r * kw + s] = r - pad; ax[r * kw + s] = s - pad; p.tap_w[r * kw + s] = r * kw + s; }
     return dispatch(p, npl, ay, ax, st);
   }
   p.Hi = Ho; p.Wi = Wo; p.Ci = Co; p.Hout = H; p.Wout = W; p.Co = Ci;
+  p.Hphys = Ho; p.Wphys = Wo;
   p.so = stride; p.si = 1;
   for (int ph = 0; ph < stride; ++ph)
     for (int pw = 0; pw < stride; ++pw) {
