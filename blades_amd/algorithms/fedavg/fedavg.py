@@ -120,10 +120,11 @@ class Fedavg(Algorithm):
 
         # "allgather" layout: every rank holds the whole update matrix and the whole theta and aggregates
         # replicated, so the server / aggregators / adversaries see a non-distributed context
-        self.update_layout = getattr(config, "update_layout", "alltoall") if self.rt.world_size > 1 else "alltoall"
+        self.update_layout = getattr(config, "update_layout", "alltoall") if self.rt.distributed else "alltoall"
         replicated = self.update_layout == "allgather"
         ctx = ShardContext(d_total=0, world_size=1 if replicated else self.rt.world_size,
-                           rank=0 if replicated else self.rt.rank)
+                           rank=0 if replicated else self.rt.rank,
+                           force=self.rt.force_collectives and not replicated)
         self.server = config.get_server_config().build(self.device, ctx=ctx)
         self.ctx = self.server.ctx
         if replicated:
@@ -163,7 +164,8 @@ class Fedavg(Algorithm):
     def _engine_runtime(self):
         from blades_amd.parallel.runtime import Runtime
 
-        return Runtime(self.rt.rank, self.rt.world_size, self.rt.local_rank, self.device, self.rt.backend)
+        return Runtime(self.rt.rank, self.rt.world_size, self.rt.local_rank, self.device, self.rt.backend,
+                       force_collectives=self.rt.force_collectives)
 
     def _setup_worker_group(self):
         wg = self.config.get_worker_group_config().build(device=str(self.device))

@@ -50,7 +50,7 @@ class Server(LearningRateSchedule):
         self.ctx = ctx if ctx is not None else local_context(D)
         self.ctx.d_total = D
         G = self.ctx.world_size
-        self.Dl = padded_width(D, G) if G > 1 else D
+        self.Dl = self.ctx.d_local
         dev = params[0].device if params else torch.device(self.device)
         self.theta = torch.zeros(self.Dl * G, dtype=torch.float32, device=dev)
         off = 0
@@ -62,7 +62,7 @@ class Server(LearningRateSchedule):
                 off += n
         self.D = D
         self.momentum_buf = torch.zeros(self.Dl, dtype=torch.float32, device=dev) if self.momentum else None
-        if G > 1:  # identical start on every rank
+        if self.ctx.distributed:  # identical start on every rank
             self.ctx.broadcast(self.theta, src=0)
 
     def _create_aggregator(self, config):

@@ -114,9 +114,9 @@ class ClientEngine:
         self.offsets = np.concatenate([[0], np.cumsum(self.numels)]).astype(np.int64)
         self.D = int(self.offsets[-1])
         G = runtime.world_size
-        self.Dl = padded_width(self.D, G) if G > 1 else self.D
+        self.ctx = ShardContext(d_total=self.D, world_size=G, rank=runtime.rank, force=runtime.force_collectives)
+        self.Dl = self.ctx.d_local
         self.Dpad = self.Dl * G
-        self.ctx = ShardContext(d_total=self.D, world_size=G, rank=runtime.rank)
 
         # ---- plan rows, collect per-client fused specs
         self.K = len(clients)
@@ -129,7 +129,7 @@ class ClientEngine:
         # ---- resident data
         ids = [clients[i].client_id for i in self.local_ids]
         self._train_rows = np.array([r for r, i in enumerate(self.local_ids) if self._trains[r]], dtype=np.int64)
-        if G > 1:
+        if self.ctx.distributed:
             # at least two chunks per rank: the all-to-all piece of the first travels while the second trains
             # (all ranks must agree on the piece count, so the rule uses the largest per-rank training load)
             most = max(sum(1 for c in rc if trains[c]) for rc in self.plan.rank_clients)
@@ -147,7 +147,7 @@ class ClientEngine:
         # unpadded D: rows that start float4-aligned are what the streaming kernels' vector paths need
         # (Mean over 1000 x 11.2 M: 7.5 ms with aligned rows, 31 ms without).
         ld = padded_width(self.Dpad, 1)
-        self.layout = update_layout if G > 1 else "alltoall"
+        self.layout = update_layout if self.ctx.distributed else "alltoall"
         if self.layout == "allgather":
             # the full [K, D] matrix lives on every rank; this rank's clients write straight into their rows of
             # it, peers' rows arrive there: no staging copy on either side
@@ -158,13 +158,12 @@ class ClientEngine:
         else:
             self._U_store = torch.zeros(self.Kloc, ld, dtype=torch.float32, device=self.device)
             self.U_row = self._U_store[:, : self.Dpad]
-            self.U_col = self.U_row if G == 1 else torch.zeros(self.K, self.Dl, dtype=torch.float32,
-                                                                device=self.device)
+            self.U_col = self.U_row if not self.ctx.distributed else torch.zeros(
+                self.K, self.Dl, dtype=torch.float32, device=self.device)
         # Client chunks alternate over HIP streams so that one chunk's bandwidth-bound kernels (per-client BN,
         # elementwise) overlap another chunk's MFMA-bound convolutions: +3 % on the headline round with two
-        # streams.  Multi-GPU runs keep one stream — there the gap is filled by the all-to-all pieces instead,
-        # which are issued between chunks on the main stream.
-        default_streams = "2" if (self.device.type == "cuda" and runtime.world_size == 1) else "1"
+        # streams.  Multi-GPU runs do the same; their exchange pieces are issued one chunk behind (train_round).
+        default_streams = "2" if self.device.type == "cuda" else "1"
         self.n_streams = max(1, int(os.environ.get("BLADES_CHUNK_STREAMS", default_streams)))
         # HIP-graph capture of a FedSGD chunk (see _graphed_chunk): "auto" turns it on for launch-bound rounds
         self.hip_graphs = os.environ.get("BLADES_HIP_GRAPH", "auto").lower()
@@ -681,6 +680,8 @@ class ClientEngine:
             n_streams = 1  # launch-bound rounds gain nothing from a second stream; keep replays in sequence
         streams = self._chunk_streams(n_streams)
         pending = []
+        done = []  # per chunk: event at its end on its stream (streamed mode, when pieces are shipped early)
+        early = self.ctx.distributed and not late
         with torch.enable_grad():
             for ci, c0 in enumerate(range(0, len(batched), self.chunk)):
                 ks = np.array(batched[c0: c0 + self.chunk], dtype=np.int64)
@@ -695,9 +696,21 @@ class ClientEngine:
                         losses = self._train_chunk_general(theta, rows, ks)
                     benign = self._chunk_consts(rows)[1]
                     pending.append(((losses.double() * benign).sum(), benign.sum()))
-                if st is None and not late and c0 + self.chunk < len(batched):
-                    # everything below the next untrained row is final: ship it while the next chunk trains
-                    self._exchange_upto(int(self._train_rows[batched[c0 + self.chunk]]))
+                    if st is not None and early:
+                        done.append(st.record_event())
+                if not early:
+                    continue
+                if st is None:
+                    if c0 + self.chunk < len(batched):
+                        # everything below the next untrained row is final: ship it while the next chunk trains
+                        self._exchange_upto(int(self._train_rows[batched[c0 + self.chunk]]))
+                elif ci >= 1:
+                    # Streamed chunks: ship one chunk behind.  The main stream (which orders the pack copy and the
+                    # sends) waits for chunk ci-1 only — it has waited for all earlier ones in earlier iterations
+                    # — so chunk ci, just launched on another stream, keeps the GPU busy meanwhile, and chunk
+                    # ci+1 (same stream as ci-1 with two streams) inherits no dependency it did not have.
+                    torch.cuda.current_stream().wait_event(done[ci - 1])
+                    self._exchange_upto(int(self._train_rows[batched[c0]]))
         for st in streams or []:
             torch.cuda.current_stream().wait_stream(st)
         for ls, cnt in pending:

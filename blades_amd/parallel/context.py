@@ -29,16 +29,17 @@ class ShardContext:
     world_size: int = 1
     rank: int = 0
     group: Optional[object] = None
+    force: bool = False  # take the distributed paths with one rank too (``Runtime.force_collectives``)
     # statistics, filled by users (bytes moved per round etc.)
     stats: dict = field(default_factory=dict)
 
     @property
     def d_local(self) -> int:
-        return padded_width(self.d_total, self.world_size) if self.world_size > 1 else self.d_total
+        return padded_width(self.d_total, self.world_size) if self.distributed else self.d_total
 
     @property
     def col_offset(self) -> int:
-        return self.rank * self.d_local if self.world_size > 1 else 0
+        return self.rank * self.d_local if self.distributed else 0
 
     @property
     def d_valid(self) -> int:
@@ -47,18 +48,18 @@ class ShardContext:
 
     @property
     def distributed(self) -> bool:
-        return self.world_size > 1
+        return self.world_size > 1 or self.force
 
     # -- collectives -----------------------------------------------------
     def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
-        if self.world_size > 1:
+        if self.distributed:
             dist.all_reduce(t, op=op, group=self.group)
             self.stats["allreduce_bytes"] = self.stats.get("allreduce_bytes", 0) + t.numel() * t.element_size()
         return t
 
     def all_gather_cols(self, local: torch.Tensor) -> torch.Tensor:
         """``[.., d_local]`` slices -> ``[.., D]`` (padding stripped)."""
-        if self.world_size == 1:
+        if not self.distributed:
             return local
         parts = [torch.empty_like(local) for _ in range(self.world_size)]
         dist.all_gather(parts, local.contiguous(), group=self.group)
@@ -66,12 +67,12 @@ class ShardContext:
         return full[..., : self.d_total]
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
-        if self.world_size > 1:
+        if self.distributed:
             dist.broadcast(t, src=src, group=self.group)
         return t
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.distributed:
             dist.barrier(group=self.group)
 
 

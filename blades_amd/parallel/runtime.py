@@ -25,6 +25,10 @@ class Runtime:
     device: torch.device = torch.device("cpu")
     backend: Optional[str] = None
     owns_group: bool = False
+    # ``BLADES_FORCE_COLLECTIVES=1``: join a process group and take every distributed code path (padded column
+    # shards, exchange, all-reduces, object gathers) even with one rank.  This is how a one-GPU box exercises
+    # the RCCL backend end to end (tests/test_rccl_single_rank.py).
+    force_collectives: bool = False
 
     @property
     def is_main(self) -> bool:
@@ -32,7 +36,7 @@ class Runtime:
 
     @property
     def distributed(self) -> bool:
-        return self.world_size > 1
+        return self.world_size > 1 or self.force_collectives
 
 
 _runtime: Optional[Runtime] = None
@@ -76,7 +80,8 @@ def init_runtime(use_gpu: Optional[bool] = None, timeout_s: Optional[int] = None
         device = torch.device("cpu")
     backend = None
     owns = False
-    if world > 1:
+    force = os.environ.get("BLADES_FORCE_COLLECTIVES", "0") == "1"
+    if world > 1 or force:
         backend = "nccl" if use_gpu else "gloo"
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", DEFAULT_MASTER_ADDR)
@@ -87,7 +92,7 @@ def init_runtime(use_gpu: Optional[bool] = None, timeout_s: Optional[int] = None
             dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                     timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
             owns = True
-    _runtime = Runtime(rank, world, local_rank, device, backend, owns)
+    _runtime = Runtime(rank, world, local_rank, device, backend, owns, force)
     heartbeat("init")
     return _runtime
 
