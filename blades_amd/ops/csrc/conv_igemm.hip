@@ -6,6 +6,11 @@
 // One "tap table" form covers every convolution of the FedSGD fast path (reference hot loop: Task.train_one_batch,
 // fllib/tasks/task.py:170-186, which runs them through cuDNN):
 //   * forward, any stride/padding:       si = stride, so = 1, taps = all (r, s), ay = r - pad, ax = s - pad
+//   * forward, stride s > 1, H and W multiples of s: the reduction runs over *segments*, one per input parity class
+//                                        (py, px): a stride-1 problem on the view in[:, py::s, px::s] with the taps
+//                                        whose r - pad = s*ay + py (and likewise in x).  Only one class of the
+//                                        receptive field is in LDS at a time, so the tile is as large as a stride-1
+//                                        layer's (64*4 pixels) instead of a quarter of it.
 //   * data gradient, stride 1:           in = gy, taps (r, s) -> ay = pad - r, ax = pad - s, W transposed
 //   * data gradient, stride s > 1:       one launch per output parity class (ph, pw): so = s, taps = the (r, s)
 //                                        with (ph + pad - r) % s == 0, ay = (ph + pad - r) / s   (no zero-stuffing)
@@ -47,6 +52,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int KC = 32;        // input channels per K-step = K of one 16x16x32 MFMA
 constexpr int BN = 64;        // output channels per workgroup
 constexpr int MAXTAPS = 25;
+constexpr int MAXSEG = 16;    // reduction segments (input parity classes of a strided forward convolution)
 constexpr int LDS_TOTAL = 160 * 1024;
 // two workgroups per CU (<= 80 KB LDS, <= 256 registers each); three smaller ones measured slower (MF = 2: 5.7 vs
 // 5.2 ms on the 64-channel layer: the weight-fragment reads per MFMA double)
@@ -71,6 +77,9 @@ struct IgemmParams {
   int n_clients, imgs_per_client;  // per-client weights (local steps > 1): image n uses weight set n / imgs_per_client
   long wp_client_stride, bias_client_stride;  // elements between two clients' weight planes / biases
   int ablate;                 // diagnostics (BLADES_IGEMM_ABLATE): 1 no staging loads, 2 no commit, 4 no MFMAs
+  int nseg;                   // reduction segments: segment g = taps [seg_begin[g], seg_begin[g + 1]) on the input view
+  int seg_begin[MAXSEG + 1];  // that starts seg_goff[g] elements into the image (all views have the same size)
+  long seg_goff[MAXSEG];
   int Hphys, Wphys, in_rm, in_cm;  // the input may be a strided view in[:, ::rm, ::cm] of a [Hphys][Wphys] image (a
                                    // strided 1x1 convolution only ever touches those pixels: it runs as a stride-1
                                    // convolution on the view, staging a quarter of the pixels)
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   constexpr int CPL = SPLIT ? 4 : 8, LPP = KC / CPL, PIXPP = 256 / LPP;
   const int cg = tid % LPP, pp = tid / LPP;
   struct ADesc { long goff; int slot; };
-  auto a_desc = [&](int pass) {
+  auto a_desc = [&](int pass, int seg) {
     ADesc d;
     const int e = pass * PIXPP + pp;
     const int il = fdiv(e, p.inv_irwi), rem = e - il * p.IR * p.Wi;
@@ -148,7 +157,9 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     const int iy = iy_lo + r;
     const bool ok = e < p.region_px && (unsigned)iy < (unsigned)p.Hi && img0 + il < p.N;
     d.slot = il * p.IS + r * p.WS + ix + p.PL;
-    d.goff = ok ? (((long)(img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci : -1;
+    d.goff = ok ? (((long)(img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci +
+                      p.seg_goff[seg]
+                : -1;
     return d;
   };
   const bool vec_in = (p.Ci % CPL) == 0;
@@ -190,14 +201,14 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     }
   };
   // whole-chunk staging with every load of a batch in flight before the first conversion
-  auto a_stage_sync = [&](int pass_begin, int c0) {
+  auto a_stage_sync = [&](int pass_begin, int c0, int seg) {
     for (int j0 = pass_begin; j0 < p.npass; j0 += 4) {
       ADesc d[4];
       u32x4 v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         d[j].goff = -1; d[j].slot = 0;
-        if (j0 + j < p.npass) d[j] = a_desc(j0 + j);
+        if (j0 + j < p.npass) d[j] = a_desc(j0 + j, seg);
         v[j] = a_load(d[j], c0);
       }
 #pragma unroll
@@ -222,19 +233,25 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   const int nchunks = p.Cip / KC, nsteps = nchunks * p.ntaps;
   __syncthreads();  // zero fill complete
   if (nsteps > 0) {
-    a_stage_sync(0, 0);
+    a_stage_sync(0, 0, 0);
 #pragma unroll
     for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q);
   }
   __syncthreads();
 
   const unsigned char* Bb = B_lds + li * 64 + ((kg * 16) ^ swz(li));
-  int c = 0, t = 0;
+  // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
+  // (segment, chunk) pair changes
+  int g = 0, c = 0, t = 0;
   for (int ks = 0; ks < nsteps; ++ks) {
-    int tn = t + 1, cn = c;
-    if (tn == p.ntaps) { tn = 0; cn = c + 1; }
-    const bool next_b = ks + 1 < nsteps && !(p.ablate & 1);
-    const bool next_a = tn == 0 && cn < nchunks && !(p.ablate & 1);  // this step ends chunk c: restage A after it
+    int tn = t + 1, cn = c, gn = g;
+    if (tn == p.seg_begin[g + 1]) {
+      tn = p.seg_begin[g]; cn = c + 1;
+      if (cn == nchunks) { cn = 0; gn = g + 1; tn = p.seg_begin[g + 1]; }
+    }
+    const bool more = ks + 1 < nsteps;
+    const bool next_b = more && !(p.ablate & 1);
+    const bool next_a = more && (cn != c || gn != g) && !(p.ablate & 1);  // this step ends (g, c): restage A after it
     // 1. global loads: next step's weight tile; at a chunk's last tap also the next chunk of the input tile.
     //    They complete under this step's MFMAs (and under the MFMAs of the workgroup sharing the CU).
     u32x4 breg[NPL];
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
 #pragma unroll
       for (int j = 0; j < MAXPF; ++j) {
         areg[j] = u32x4{0, 0, 0, 0};
-        if (j < p.npass) areg[j] = a_load(a_desc(j), cn * KC);
+        if (j < p.npass) areg[j] = a_load(a_desc(j, gn), cn * KC);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -293,11 +310,11 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     if (next_a && !(p.ablate & 2)) {
 #pragma unroll
       for (int j = 0; j < MAXPF; ++j)
-        if (j < p.npass) a_store(a_desc(j), areg[j]);
-      a_stage_sync(MAXPF, cn * KC);  // geometries with more than MAXPF passes: the rest without prefetch
+        if (j < p.npass) a_store(a_desc(j, gn), areg[j]);
+      a_stage_sync(MAXPF, cn * KC, gn);  // geometries with more than MAXPF passes: the rest without prefetch
     }
     __syncthreads();
-    t = tn; c = cn;
+    t = tn; c = cn; g = gn;
   }
 
   // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
@@ -453,6 +470,7 @@ int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t 
   p.inv_ws = 1.0f / p.Ws; p.inv_tr = 1.0f / p.TR; p.inv_wi = 1.0f / p.Wi; p.inv_irwi = 1.0f / (p.IR * p.Wi);
   for (int t = 0; t < p.ntaps; ++t) p.tap_off[t] = (ay[t] - p.aymin) * p.WS + ax[t];
   p.n_ntiles = p.Cop / BN;
+  if (p.nseg == 0) { p.nseg = 1; p.seg_begin[0] = 0; p.seg_begin[1] = p.ntaps; p.seg_goff[0] = 0; }
   { const char* e = getenv("BLADES_IGEMM_ABLATE"); p.ablate = e ? atoi(e) : 0; }
 #define GO(NPL, SPLIT)                                           \
   do {                                                           \
@@ -515,6 +533,34 @@ BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bi
       p.Hi = Ho; p.Wi = Wo; p.si = 1; p.in_rm = p.in_cm = stride;
     }
     p.ntaps = taps;
+    static const bool seg_off = [] { const char* e = getenv("BLADES_IGEMM_SEGMENTS"); return e && atoi(e) == 0; }();
+    if (taps > 1 && stride > 1 && H % stride == 0 && W % stride == 0 && stride * stride <= MAXSEG && !seg_off) {
+      // one reduction segment per input parity class: stride-1 taps on the view in[:, py::stride, px::stride]
+      auto fl = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+      p.Hi = H / stride; p.Wi = W / stride; p.si = 1; p.in_rm = p.in_cm = stride;
+      int n = 0;
+      p.nseg = 0;
+      for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+          const int n0 = n;
+          for (int r = 0; r < kh; ++r) {
+            const int a = fl(r - pad, stride);
+            if (r - pad - a * stride != py) continue;
+            for (int s = 0; s < kw; ++s) {
+              const int b = fl(s - pad, stride);
+              if (s - pad - b * stride != px) continue;
+              ay[n] = a; ax[n] = b; p.tap_w[n] = r * kw + s;
+              ++n;
+            }
+          }
+          if (n == n0) continue;
+          p.seg_begin[p.nseg] = n0;
+          p.seg_goff[p.nseg] = ((long)py * W + px) * Ci;
+          ++p.nseg;
+        }
+      p.seg_begin[p.nseg] = n;
+      return dispatch(p, npl, ay, ax, st);
+    }
     for (int r = 0; r < kh; ++r)
       for (int s = 0; s < kw; ++s) { ay[r * kw + s] = r - pad; ax[r * kw + s] = s - pad; p.tap_w[r * kw + s] = r * kw + s; }
     return dispatch(p, npl, ay, ax, st);
