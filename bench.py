@@ -82,8 +82,9 @@ def main():
     f = int(round(args.malicious_frac * K))
     agg = {"type": args.aggregator}
     # fp32 planes: the MFMA-bound kernels are already full at 40 clients x 64 samples, and the smaller working set
-    # (53 GB peak instead of 102 GB) is worth 5 % (profiles/r2_chunk_stream_sweep_fp32.txt); bf16 likes 400
-    chunk = args.chunk or (400 if args.amp == "bf16" else 40)
+    # (53 GB peak instead of 102 GB) is worth 5 % (profiles/r2_chunk_stream_sweep_fp32.txt, 32 clients on three
+    # streams: profiles/r2_chunk_stream_sweep_v6.txt); bf16 likes 400
+    chunk = args.chunk or (400 if args.amp == "bf16" else 32)
     if world > 1:
         # at least two chunks per rank, so the all-to-all of the first overlaps the training of the second
         chunk = max(1, min(chunk, -(-(K - f) // (2 * world))))

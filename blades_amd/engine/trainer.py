@@ -80,11 +80,11 @@ class ClientEngine:
             # proportionally fewer clients so that activation memory stays put.  CPU runs keep chunks small.
             on_gpu = self.device.type == "cuda"
             clients_per_chunk = max(8, min(200, (200 * 64) // max(int(batch_size), 1))) if on_gpu else 64
-            # fp32 planes on a large convolutional model: the MFMA-bound kernels are full at 40 x 64 samples and the
-            # smaller working set is worth 5 % (profiles/r2_chunk_stream_sweep_fp32.txt)
+            # fp32 planes on a large convolutional model: the MFMA-bound kernels are full at 32-40 x 64 samples and
+            # the smaller working set is worth 5 % (profiles/r2_chunk_stream_sweep_fp32.txt, ..._v6.txt)
             n_par = sum(p.numel() for p in task.model.parameters())
             if on_gpu and amp_dtype in ("auto", "fp32", "bf16x3", None) and n_par > 8_000_000:
-                clients_per_chunk = max(8, clients_per_chunk // 5)
+                clients_per_chunk = max(8, clients_per_chunk // 6)
         self.chunk = max(1, int(clients_per_chunk))
         self.eval_chunk = eval_clients_per_chunk or self.chunk
         self.num_classes = num_classes
@@ -162,8 +162,9 @@ class ClientEngine:
                 self.K, self.Dl, dtype=torch.float32, device=self.device)
         # Client chunks alternate over HIP streams so that one chunk's bandwidth-bound kernels (per-client BN,
         # elementwise) overlap another chunk's MFMA-bound convolutions: +3 % on the headline round with two
-        # streams.  Multi-GPU runs do the same; their exchange pieces are issued one chunk behind (train_round).
-        default_streams = "2" if self.device.type == "cuda" else "1"
+        # streams, another 1 % with three (four are slower; profiles/r2_chunk_stream_sweep_v6.txt).  Multi-GPU
+        # runs do the same; their exchange pieces are issued one chunk behind (train_round).
+        default_streams = "3" if self.device.type == "cuda" else "1"
         self.n_streams = max(1, int(os.environ.get("BLADES_CHUNK_STREAMS", default_streams)))
         # HIP-graph capture of a FedSGD chunk (see _graphed_chunk): "auto" turns it on for launch-bound rounds
         self.hip_graphs = os.environ.get("BLADES_HIP_GRAPH", "auto").lower()
@@ -683,8 +684,11 @@ class ClientEngine:
         done = []  # per chunk: event at its end on its stream (streamed mode, when pieces are shipped early)
         early = self.ctx.distributed and not late
         with torch.enable_grad():
-            for ci, c0 in enumerate(range(0, len(batched), self.chunk)):
-                ks = np.array(batched[c0: c0 + self.chunk], dtype=np.int64)
+            # equal-sized chunks (100 clients at 40 per chunk: 34 + 33 + 33, not 40 + 40 + 20)
+            n_chunks = max(1, -(-len(batched) // self.chunk))
+            per = max(1, -(-len(batched) // n_chunks))
+            for ci, c0 in enumerate(range(0, len(batched), per)):
+                ks = np.array(batched[c0: c0 + per], dtype=np.int64)
                 rows = self._train_rows[ks]
                 st = streams[ci % len(streams)] if streams else None
                 if st is not None:
@@ -701,9 +705,9 @@ class ClientEngine:
                 if not early:
                     continue
                 if st is None:
-                    if c0 + self.chunk < len(batched):
+                    if c0 + per < len(batched):
                         # everything below the next untrained row is final: ship it while the next chunk trains
-                        self._exchange_upto(int(self._train_rows[batched[c0 + self.chunk]]))
+                        self._exchange_upto(int(self._train_rows[batched[c0 + per]]))
                 elif ci >= 1:
                     # Streamed chunks: ship one chunk behind.  The main stream (which orders the pack copy and the
                     # sends) waits for chunk ci-1 only — it has waited for all earlier ones in earlier iterations
