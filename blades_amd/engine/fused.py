@@ -82,6 +82,8 @@ _DGRAD_AS_FWD = _os.environ.get("BLADES_DGRAD_AS_FWD", "1") != "0"
 # "hip" (default): forward and data-gradient convolutions run ops/csrc/conv_igemm.hip; "miopen": the library's
 # kernels (A/B comparisons only — the fp32 library path has no matrix-core kernel on gfx950)
 _CONV_IMPL = _os.environ.get("BLADES_CONV_IMPL", "hip").lower()
+# BatchNorm statistics from the convolution kernel's epilogue (0: separate statistics pass, for A/B runs)
+_BN_STATS_IN_CONV = _os.environ.get("BLADES_BN_STATS_IN_CONV", "1") != "0"
 
 
 def _own_conv(x, mod) -> bool:
@@ -105,9 +107,10 @@ def dgrad_same_conv(gy: torch.Tensor, w: torch.Tensor, padding) -> torch.Tensor:
 
 class _PCConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, mod):
+    def forward(ctx, x, weight, mod, want_stats=False):
         w = weight.to(x.dtype)
         b = mod.bias.to(x.dtype) if mod.bias is not None else None
+        mod.bn_stats = None
         if x.is_cuda and x.dim() == 4:
             # keep the whole network in NHWC: MIOpen's bf16 kernels are NHWC (an NCHW input is transposed
             # around every call) and so are the per-client BN / wgrad kernels.  A one-channel image is
@@ -124,6 +127,12 @@ class _PCConvFn(torch.autograd.Function):
             # the shared ones, or each client's own set when the sink carries per-client weights
             wk = mod.sink.param(weight).detach()
             ctx.save_for_backward(x, wk)
+            Kc = mod.sink.Kc
+            if want_stats and mod.sink.npl > 1 and Kc and x.shape[0] % Kc == 0 and _BN_STATS_IN_CONV:
+                # the BatchNorm that follows gets its per-client sums from this kernel's epilogue
+                y, mod.bn_stats = _hipmod().conv_forward(x, wk, mod.sink.param(mod.bias), int(mod.stride[0]),
+                                                         int(mod.padding[0]), mod.sink.npl, stats_B=x.shape[0] // Kc)
+                return y
             return _hipmod().conv_forward(x, wk, mod.sink.param(mod.bias), int(mod.stride[0]), int(mod.padding[0]),
                                           mod.sink.npl)
         if mod.sink.W is not None:
@@ -162,7 +171,7 @@ class _PCConvFn(torch.autograd.Function):
             # per-client bias gradient: fp32 accumulation straight from the (NHWC) bf16 tensor, no fp32 copy
             g = gy.permute(0, 2, 3, 1) if gy.dim() == 4 else gy.unsqueeze(1)
             sink.write(mod.bias, g.reshape(Kc, -1, gy.shape[1]).sum(dim=1, dtype=torch.float32))
-        return dx, None, None
+        return dx, None, None, None
 
 
 class PCConv2d(nn.Module):
@@ -172,9 +181,10 @@ class PCConv2d(nn.Module):
         self.weight, self.bias = conv.weight, conv.bias
         self.stride, self.padding, self.dilation = list(conv.stride), list(conv.padding), list(conv.dilation)
         self.sink = sink
+        self.bn_stats = None  # (partial, nchunk) of the last forward(..., want_stats=True), consumed by the BN
 
-    def forward(self, x):
-        return _PCConvFn.apply(x, self.weight, self)
+    def forward(self, x, want_stats: bool = False):
+        return _PCConvFn.apply(x, self.weight, self, want_stats)
 
     def wgrad_hip(self, x, gy, Kc) -> bool:
         """MFMA kernel path: dW_c lands, scaled, in the update-matrix rows.  False = not applicable."""
@@ -329,14 +339,14 @@ class _PCBatchNormFn(torch.autograd.Function):
     torch reference above."""
 
     @staticmethod
-    def forward(ctx, x, res, anchor, mod, relu):
+    def forward(ctx, x, res, anchor, mod, relu, pre_stats=None):
         sink: GradSink = mod.sink
         Kc = sink.Kc
         use_hip = x.is_cuda and _hipmod().pcbn_supported(x) and (res is None or _hipmod().pcbn_supported(res))
         if use_hip:
             # the kernel leaves the ReLU gate as a bitmask (1/16 of y's bytes) for the backward pass
             y, mean, invstd, gate = _hipmod().pcbn_forward(x, res, sink.param(mod.weight), sink.param(mod.bias),
-                                                           Kc, mod.eps, relu, want_mask=True)
+                                                           Kc, mod.eps, relu, want_mask=True, pre_stats=pre_stats)
         elif sink.W is not None:
             raise NotImplementedError("per-client weights need the hand-written batch-norm kernels")
         else:
@@ -371,7 +381,7 @@ class _PCBatchNormFn(torch.autograd.Function):
                 sink.write(mod.bias, dbeta)
         if ctx.has_res and not ctx.relu:
             gres = gy
-        return dx, (gres if ctx.has_res else None), None, None, None
+        return dx, (gres if ctx.has_res else None), None, None, None, None
 
 
 def _hipmod():
@@ -564,9 +574,19 @@ class PCBatchNorm2d(nn.Module):
         self.bias = bn.bias if bn.affine else None
         self.sink = sink
 
-    def forward(self, x, residual=None, relu: bool = False):
+    def forward(self, x, residual=None, relu: bool = False, pre_stats=None):
         anchor = self.weight if self.weight is not None else x
-        return _PCBatchNormFn.apply(x, residual, anchor, self, relu)
+        return _PCBatchNormFn.apply(x, residual, anchor, self, relu, pre_stats)
+
+
+def _conv_bn(conv, bn, x, residual=None, relu: bool = False):
+    """``bn(conv(x))`` with the BatchNorm statistics taken from the convolution kernel's epilogue when both are
+    the engine's own modules (no separate statistics pass over the convolution output)."""
+    if isinstance(conv, PCConv2d) and isinstance(bn, PCBatchNorm2d):
+        y = conv(x, want_stats=True)
+        pre, conv.bn_stats = conv.bn_stats, None
+        return bn(y, residual=residual, relu=relu, pre_stats=pre)
+    return bn(conv(x), residual=residual, relu=relu)
 
 
 class PCResBlock(nn.Module):
@@ -581,12 +601,12 @@ class PCResBlock(nn.Module):
         b = self.blk
         sc = x
         if len(b.shortcut) > 0:
-            sc = b.shortcut[1](b.shortcut[0](x))
-        out = b.bn1(b.conv1(x), relu=True)
+            sc = _conv_bn(b.shortcut[0], b.shortcut[1], x)
+        out = _conv_bn(b.conv1, b.bn1, x, relu=True)
         if self.bottleneck:
-            out = b.bn2(b.conv2(out), relu=True)
-            return b.bn3(b.conv3(out), residual=sc, relu=True)
-        return b.bn2(b.conv2(out), residual=sc, relu=True)
+            out = _conv_bn(b.conv2, b.bn2, out, relu=True)
+            return _conv_bn(b.conv3, b.bn3, out, residual=sc, relu=True)
+        return _conv_bn(b.conv2, b.bn2, out, residual=sc, relu=True)
 
 
 class PCResNet(nn.Module):
@@ -596,7 +616,7 @@ class PCResNet(nn.Module):
 
     def forward(self, x):
         n = self.net
-        out = n.bn1(n.conv1(x), relu=True)
+        out = _conv_bn(n.conv1, n.bn1, x, relu=True)
         out = n.layer4(n.layer3(n.layer2(n.layer1(out))))
         out = F.avg_pool2d(out, 4)
         return n.linear(out.reshape(out.size(0), -1))

@@ -57,7 +57,7 @@ _augment = _sig("blades_augment_batch", [_P, _P, _P, c_int, c_int, c_int, c_int,
 
 _pcbn_nchunk = _sig("blades_pcbn_nchunk", [c_int, c_int, c_int], c_int)
 _pcbn_fwd = _sig("blades_pcbn_forward", [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
-                                         c_int, c_int, _P], c_int)
+                                         c_int, c_int, c_int, _P], c_int)
 _pcbn_bwd = _sig("blades_pcbn_backward", [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_long, c_long, c_long,
                                           c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P], c_int)
 
@@ -438,7 +438,9 @@ def pcbn_supported(x: torch.Tensor) -> bool:
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask: bool = False):
+def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask: bool = False, pre_stats=None):
+    """``pre_stats``: ``(partial, nchunk)`` from ``conv_forward(..., stats_B=...)`` — the convolution that produced
+    ``x`` already summed it per (client, tile, channel), so the statistics pass over ``x`` is skipped."""
     if x.dtype not in _ACT_DTYPES:
         raise ValueError(f"pcbn_forward: unsupported dtype {x.dtype}")
     _chk_nhwc_bf16(x, "x", x.dtype)
@@ -455,15 +457,22 @@ def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask
     beta, bstride = _affine(beta, Kc, C, dev, "beta")
     if gamma is not None and beta is not None and gstride != bstride:
         raise ValueError("pcbn_forward: gamma and beta must both be shared or both per client")
-    nch = _pcbn_nchunk(P, C, x.element_size())
-    partial = _empty(Kc * nch * C * 2, device=dev)
+    pre_nch = 0
+    if pre_stats is not None:
+        partial, pre_nch = pre_stats
+        if not (partial.is_cuda and partial.dtype == torch.float32 and partial.is_contiguous()
+                and pre_nch > 0 and partial.numel() == Kc * pre_nch * C * 2):
+            raise ValueError("pcbn_forward: pre_stats does not match [Kc, nchunk, C, 2]")
+    else:
+        nch = _pcbn_nchunk(P, C, x.element_size())
+        partial = _empty(Kc * nch * C * 2, device=dev)
     stats = _empty(4, Kc, C, device=dev)
     y = _empty_like(x)
     # ReLU gate for the backward pass: 1 bit per element (8 channels of a pixel = 1 byte) instead of y itself
     mask = _empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (relu and want_mask) else None
     rc = _pcbn_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), Kc, P, C, eps, int(relu), _ptr(partial),
                    _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(y), _ptr(mask), x.element_size(),
-                   gstride, _stream())
+                   gstride, int(pre_nch), _stream())
     if rc != 0:
         raise ValueError("pcbn_forward: unsupported shape")
     if want_mask:
@@ -882,7 +891,8 @@ def linear_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, npl
 # ---------------------------------------------------------------------------
 # shared-weight convolution: forward and data gradient (ops/csrc/conv_igemm.hip)
 _conv_igemm_ws = _sig("blades_conv_igemm_ws", [c_int] * 7, c_long)
-_conv_igemm = _sig("blades_conv_igemm", [_P, _P, _P, _P, _P] + [c_int] * 14 + [c_long, c_long, _P], c_int)
+_conv_igemm = _sig("blades_conv_igemm", [_P, _P, _P, _P, _P] + [c_int] * 14 + [c_long, c_long, _P, c_int, _P], c_int)
+_conv_igemm_stats_nchunk = _sig("blades_conv_igemm_stats_nchunk", [c_int] * 14, c_int)
 
 #: operand planes per compute dtype: fp32 tensors are split exactly into 3 bf16 planes (6 MFMA products, fp32
 #: grade), "bf16x3" keeps 2 planes (3 products, ~2^-17), bf16 tensors run as they are
@@ -906,7 +916,7 @@ def conv_igemm_supported(x: torch.Tensor, weight: torch.Tensor, stride, pad, dil
             and x.shape[3] + 2 * pad[1] >= kw and x.shape[3] <= 256)
 
 
-def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, mode, npl):
+def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, mode, npl, stats_B=0):
     """``weight``: [Co, Ci, kh, kw] shared by every image, or [Kc, Co, Ci, kh, kw] — one weight set per client
     (clients may be rows of a wider matrix: any stride along dim 0, contiguous inside a client)."""
     w = weight.detach()
@@ -928,15 +938,25 @@ def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, 
         else:
             bias = _vec(b, Co, inp.device, name="bias")
     ws = _empty(_conv_igemm_ws(Co, Ci, kh, kw, mode, npl, nc), dtype=torch.uint8, device=inp.device)
+    partial, nch = None, 0
+    if stats_B and mode == 0 and npl > 1:
+        # BatchNorm partial sums from the epilogue, when no tile of the planned launch straddles two clients
+        nch = _conv_igemm_stats_nchunk(N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, npl, nc, int(stats_B))
+        if nch > 0:
+            partial = _empty((N // int(stats_B)) * nch * Co * 2, device=inp.device)
     rc = _conv_igemm(_ptr(inp), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad,
-                     mode, npl, nc, wstride, bstride, _stream())
+                     mode, npl, nc, wstride, bstride, _ptr(partial), int(stats_B) if partial is not None else 0,
+                     _stream())
     if rc != 0:
         raise ValueError(f"conv_igemm: unsupported configuration (rc={rc}): N={N} H={H} W={W} Ci={Ci} Co={Co} "
                          f"k={kh}x{kw} stride={stride} pad={pad} mode={mode} npl={npl}")
+    return (partial, nch) if partial is not None else None
 
 
-def conv_forward(x, weight, bias, stride: int, pad: int, npl: int):
-    """y = conv2d(x, weight, bias) for channels-last x; fp32 (npl 3 / 2) or bf16 (npl 1) in and out."""
+def conv_forward(x, weight, bias, stride: int, pad: int, npl: int, stats_B: int = 0):
+    """y = conv2d(x, weight, bias) for channels-last x; fp32 (npl 3 / 2) or bf16 (npl 1) in and out.
+    ``stats_B`` > 0 (fp32 tensors, ``stats_B`` images per client): returns ``(y, pre_stats)`` where ``pre_stats`` is
+    the ``(partial, nchunk)`` pair ``pcbn_forward`` accepts, or ``None`` if this geometry cannot provide it."""
     dt = torch.bfloat16 if npl == 1 else torch.float32
     _chk_nhwc(x, "x", dt)
     N, Ci, H, W = x.shape
@@ -949,8 +969,8 @@ def conv_forward(x, weight, bias, stride: int, pad: int, npl: int):
     y = _empty((N, Co, Ho, Wo), dtype=dt, device=x.device, memory_format=torch.channels_last)
     if Co == 1 or Ho * Wo == 1:
         y = y.as_strided(y.shape, (Ho * Wo * Co, 1, Wo * Co, Co))
-    _conv_call(x, weight, bias, y, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 0, npl)
-    return y
+    pre = _conv_call(x, weight, bias, y, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 0, npl, stats_B)
+    return (y, pre) if stats_B else y
 
 
 def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int):

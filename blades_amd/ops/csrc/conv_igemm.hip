@@ -77,6 +77,9 @@ struct IgemmParams {
   int n_clients, imgs_per_client;  // per-client weights (local steps > 1): image n uses weight set n / imgs_per_client
   long wp_client_stride, bias_client_stride;  // elements between two clients' weight planes / biases
   int ablate;                 // diagnostics (BLADES_IGEMM_ABLATE): 1 no staging loads, 2 no commit, 4 no MFMAs
+  float* stats;               // forward, fp32 output: per-(client, tile, channel) sum / sum of squares of the
+  int stats_B, stats_nchunk;  // output — the first pass of the per-client BatchNorm that follows (pcbn.hip's
+                              // partial[(client * nchunk + chunk) * Co + ch][2]); stats_B = images per client
   int nseg;                   // reduction segments: segment g = taps [seg_begin[g], seg_begin[g + 1]) on the input view
   int seg_begin[MAXSEG + 1];  // that starts seg_goff[g] elements into the image (all views have the same size)
   long seg_goff[MAXSEG];
@@ -319,6 +322,10 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
 
   // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
   const bool vec_out = (p.Co % 4) == 0;
+  const bool want_stats = SPLIT && p.stats != nullptr;  // block-uniform
+  f32x4 st_s[4], st_q[4];
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf) { st_s[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; st_q[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int pf = 0; pf < MF; ++pf) {
     if (out_pix[pf] < 0) continue;
@@ -331,6 +338,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? bias_c[co + j] : 0.f;
       }
+      if (want_stats) { st_s[cf] += v; st_q[cf] += v * v; }
       if constexpr (SPLIT) {
         float* dst = reinterpret_cast<float*>(p.out) + out_pix[pf] * p.Co + co;
         if (vec_out) *reinterpret_cast<f32x4*>(dst) = v;
@@ -345,6 +353,44 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
         else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = (unsigned short)(b[j >> 1] >> ((j & 1) * 16));
+        }
+      }
+    }
+  }
+  if constexpr (SPLIT) {
+    if (want_stats) {
+      // BatchNorm statistics of this tile: fixed-order tree over the 16 pixel lanes, then over the four waves
+      // through LDS (every wave is past its last fragment read: the K loop ends with a barrier)
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            st_s[cf][j] += __shfl_xor(st_s[cf][j], o);
+            st_q[cf][j] += __shfl_xor(st_q[cf][j], o);
+          }
+      float* red = reinterpret_cast<float*>(smem);  // [4 waves][64 ch][2]
+      if (li == 0) {
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ch = cf * 16 + kg * 4 + j;
+            red[(wave * 64 + ch) * 2 + 0] = st_s[cf][j];
+            red[(wave * 64 + ch) * 2 + 1] = st_q[cf][j];
+          }
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int ch = tid >> 1, which = tid & 1;
+        if (n0 + ch < p.Co) {
+          float a = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) a += red[(w * 64 + ch) * 2 + which];
+          const int cl = img0 / p.stats_B, in_cl = img0 - cl * p.stats_B;
+          const int chunk = p.TI == 1 ? in_cl * p.tiles_per_img + (mt - img0 * p.tiles_per_img) : in_cl / p.TI;
+          p.stats[(((size_t)cl * p.stats_nchunk + chunk) * p.Co + n0 + ch) * 2 + which] = a;
         }
       }
     }
@@ -447,6 +493,13 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
   return best_mf;
 }
 
+// tiles per client of a planned forward launch (= BatchNorm partial chunks); 0: a tile would straddle two clients
+int stats_chunks(const IgemmParams& p, int B) {
+  if (B <= 0 || p.N % B != 0) return 0;
+  if (p.TI > 1) return B % p.TI == 0 ? B / p.TI : 0;
+  return B * p.tiles_per_img;
+}
+
 template <int NPL, int MF, bool SPLIT>
 int launch(const IgemmParams& p, hipStream_t st) {
   const size_t lds = (size_t)NPL * p.NS * 64 + (size_t)NPL * BN * 64;
@@ -470,6 +523,10 @@ int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t 
   p.inv_ws = 1.0f / p.Ws; p.inv_tr = 1.0f / p.TR; p.inv_wi = 1.0f / p.Wi; p.inv_irwi = 1.0f / (p.IR * p.Wi);
   for (int t = 0; t < p.ntaps; ++t) p.tap_off[t] = (ay[t] - p.aymin) * p.WS + ax[t];
   p.n_ntiles = p.Cop / BN;
+  if (p.stats != nullptr) {
+    p.stats_nchunk = stats_chunks(p, p.stats_B);
+    if (p.stats_nchunk == 0 || npl == 1) return 6;
+  }
   if (p.nseg == 0) { p.nseg = 1; p.seg_begin[0] = 0; p.seg_begin[1] = p.ntaps; p.seg_goff[0] = 0; }
   { const char* e = getenv("BLADES_IGEMM_ABLATE"); p.ablate = e ? atoi(e) : 0; }
 #define GO(NPL, SPLIT)                                           \
@@ -485,6 +542,50 @@ int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t 
   return 4;
 }
 
+// geometry and tap table of a forward convolution (p.N and the channel paddings are set by the caller)
+void fill_forward(IgemmParams& p, int* ay, int* ax, int H, int W, int Ci, int Ho, int Wo, int Co, int kh, int kw,
+                  int stride, int pad) {
+  const int taps = kh * kw;
+  p.in_rm = p.in_cm = 1;
+  p.Hi = H; p.Wi = W; p.Ci = Ci; p.Hout = Ho; p.Wout = Wo; p.Co = Co;
+  p.Hs = Ho; p.Ws = Wo; p.so = 1; p.poy = 0; p.pox = 0; p.si = stride;
+  p.Hphys = H; p.Wphys = W;
+  if (taps == 1 && pad == 0 && stride > 1) {  // strided 1x1: stride-1 on the view in[:, ::stride, ::stride]
+    p.Hi = Ho; p.Wi = Wo; p.si = 1; p.in_rm = p.in_cm = stride;
+  }
+  p.ntaps = taps;
+  static const bool seg_off = [] { const char* e = getenv("BLADES_IGEMM_SEGMENTS"); return e && atoi(e) == 0; }();
+  if (taps > 1 && stride > 1 && H % stride == 0 && W % stride == 0 && stride * stride <= MAXSEG && !seg_off) {
+    // one reduction segment per input parity class: stride-1 taps on the view in[:, py::stride, px::stride]
+    auto fl = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    p.Hi = H / stride; p.Wi = W / stride; p.si = 1; p.in_rm = p.in_cm = stride;
+    int n = 0;
+    p.nseg = 0;
+    for (int py = 0; py < stride; ++py)
+      for (int px = 0; px < stride; ++px) {
+        const int n0 = n;
+        for (int r = 0; r < kh; ++r) {
+          const int a = fl(r - pad, stride);
+          if (r - pad - a * stride != py) continue;
+          for (int s = 0; s < kw; ++s) {
+            const int b = fl(s - pad, stride);
+            if (s - pad - b * stride != px) continue;
+            ay[n] = a; ax[n] = b; p.tap_w[n] = r * kw + s;
+            ++n;
+          }
+        }
+        if (n == n0) continue;
+        p.seg_begin[p.nseg] = n0;
+        p.seg_goff[p.nseg] = ((long)py * W + px) * Ci;
+        ++p.nseg;
+      }
+    p.seg_begin[p.nseg] = n;
+    return;
+  }
+  for (int r = 0; r < kh; ++r)
+    for (int s = 0; s < kw; ++s) { ay[r * kw + s] = r - pad; ax[r * kw + s] = s - pad; p.tap_w[r * kw + s] = r * kw + s; }
+}
+
 }  // namespace
 
 // bytes of weight-plane workspace a call needs
@@ -498,11 +599,13 @@ BLADES_API long blades_conv_igemm_ws(int Co, int Ci, int kh, int kw, int mode, i
 // w: [Co][Ci][kh][kw] fp32 contiguous.  npl 3 / 2: fp32 tensors; npl 1: bf16 tensors.
 // n_clients > 1: per-client weights — image n uses the weight set n / (N / n_clients), found at
 // w + client * w_client_stride (bias + client * bias_client_stride); the FedSGD fast path passes n_clients = 1.
+// stats != null (forward, fp32 tensors): also writes the per-client BatchNorm partial sums of the output,
+// [N / stats_B clients][blades_conv_igemm_stats_nchunk(...) chunks][Co][2] floats.
 // returns 0 ok; nonzero = unsupported (caller falls back)
 BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
                                  int W, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad, int mode,
                                  int npl, int n_clients, long w_client_stride, long bias_client_stride,
-                                 hipStream_t st) {
+                                 float* stats, int stats_B, hipStream_t st) {
   if (npl < 1 || npl > 3 || kh * kw > MAXTAPS || stride < 1 || N <= 0) return 1;
   if (n_clients < 1) n_clients = 1;
   if (N % n_clients || n_clients > 65535) return 5;
@@ -526,45 +629,11 @@ BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bi
   int ay[MAXTAPS], ax[MAXTAPS];
   p.in_rm = p.in_cm = 1;
   if (mode == 0) {
-    p.Hi = H; p.Wi = W; p.Ci = Ci; p.Hout = Ho; p.Wout = Wo; p.Co = Co;
-    p.Hs = Ho; p.Ws = Wo; p.so = 1; p.poy = 0; p.pox = 0; p.si = stride;
-    p.Hphys = H; p.Wphys = W;
-    if (taps == 1 && pad == 0 && stride > 1) {  // strided 1x1: stride-1 on the view in[:, ::stride, ::stride]
-      p.Hi = Ho; p.Wi = Wo; p.si = 1; p.in_rm = p.in_cm = stride;
-    }
-    p.ntaps = taps;
-    static const bool seg_off = [] { const char* e = getenv("BLADES_IGEMM_SEGMENTS"); return e && atoi(e) == 0; }();
-    if (taps > 1 && stride > 1 && H % stride == 0 && W % stride == 0 && stride * stride <= MAXSEG && !seg_off) {
-      // one reduction segment per input parity class: stride-1 taps on the view in[:, py::stride, px::stride]
-      auto fl = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
-      p.Hi = H / stride; p.Wi = W / stride; p.si = 1; p.in_rm = p.in_cm = stride;
-      int n = 0;
-      p.nseg = 0;
-      for (int py = 0; py < stride; ++py)
-        for (int px = 0; px < stride; ++px) {
-          const int n0 = n;
-          for (int r = 0; r < kh; ++r) {
-            const int a = fl(r - pad, stride);
-            if (r - pad - a * stride != py) continue;
-            for (int s = 0; s < kw; ++s) {
-              const int b = fl(s - pad, stride);
-              if (s - pad - b * stride != px) continue;
-              ay[n] = a; ax[n] = b; p.tap_w[n] = r * kw + s;
-              ++n;
-            }
-          }
-          if (n == n0) continue;
-          p.seg_begin[p.nseg] = n0;
-          p.seg_goff[p.nseg] = ((long)py * W + px) * Ci;
-          ++p.nseg;
-        }
-      p.seg_begin[p.nseg] = n;
-      return dispatch(p, npl, ay, ax, st);
-    }
-    for (int r = 0; r < kh; ++r)
-      for (int s = 0; s < kw; ++s) { ay[r * kw + s] = r - pad; ax[r * kw + s] = s - pad; p.tap_w[r * kw + s] = r * kw + s; }
+    p.stats = stats; p.stats_B = stats_B;
+    fill_forward(p, ay, ax, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad);
     return dispatch(p, npl, ay, ax, st);
   }
+  if (stats != nullptr) return 6;
   p.Hi = Ho; p.Wi = Wo; p.Ci = Co; p.Hout = H; p.Wout = W; p.Co = Ci;
   p.Hphys = Ho; p.Wphys = Wo;
   p.so = stride; p.si = 1;
@@ -588,4 +657,21 @@ BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bi
       if (rc != 0) return rc;
     }
   return 0;
+}
+
+// Chunks per client of the BatchNorm partial sums a forward call with `stats` writes; 0 = not available for this
+// geometry (a tile would straddle two clients, or no tile shape fits).
+BLADES_API int blades_conv_igemm_stats_nchunk(int N, int H, int W, int Ci, int Ho, int Wo, int Co, int kh, int kw,
+                                              int stride, int pad, int npl, int n_clients, int stats_B) {
+  if (npl < 2 || npl > 3 || kh * kw > MAXTAPS || stride < 1 || N <= 0 || stats_B <= 0) return 0;
+  if (n_clients < 1) n_clients = 1;
+  if (N % n_clients) return 0;
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.N = N; p.ntw = kh * kw; p.Cop = round_up(Co, BN); p.Cip = round_up(Ci, KC);
+  p.n_clients = n_clients; p.imgs_per_client = N / n_clients;
+  int ay[MAXTAPS], ax[MAXTAPS];
+  fill_forward(p, ay, ax, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad);
+  if (plan(p, npl, ay, ax) == 0) return 0;
+  return stats_chunks(p, stats_B);
 }

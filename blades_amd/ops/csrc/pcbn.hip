@@ -254,10 +254,14 @@ inline int chunk_pixels(int C, int esize = 2) {
 template <typename T>
 int pcbn_forward_t(const void* x, const void* res, const float* gamma, const float* beta, int gstride, int Kc, int P, int C, float eps,
                    int relu, float* partial, float* mean, float* invstd, float* scale, float* shift, void* y,
-                   void* relu_mask, hipStream_t st) {
-  const int ppc = chunk_pixels(C, sizeof(T)), nch = cdiv(P, ppc);
-  hipLaunchKernelGGL((pcbn_reduce_kernel<0, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
-                     (const T*)nullptr, nullptr, nullptr, nullptr, P, C, ppc, nch, partial);
+                   void* relu_mask, int pre_nchunk, hipStream_t st) {
+  const int ppc = chunk_pixels(C, sizeof(T));
+  // pre_nchunk > 0: `partial` already holds the sums, in pre_nchunk chunks per client — written by the epilogue of
+  // the convolution that produced x (conv_igemm.hip), so x is read once here instead of twice
+  const int nch = pre_nchunk > 0 ? pre_nchunk : cdiv(P, ppc);
+  if (pre_nchunk <= 0)
+    hipLaunchKernelGGL((pcbn_reduce_kernel<0, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
+                       (const T*)nullptr, nullptr, nullptr, nullptr, P, C, ppc, nch, partial);
   hipLaunchKernelGGL(pcbn_fwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
                      eps, gamma, beta, gstride, mean, invstd, scale, shift);
   int gx = cdiv((long)P * (C / 8), TPB);
@@ -289,18 +293,18 @@ int pcbn_backward_t(const void* x, const void* gy, const void* relu_mask, const 
 // esize: bytes per activation element (2 = bf16, 4 = fp32)
 BLADES_API int blades_pcbn_nchunk(int P, int C, int esize) { return cdiv(P, chunk_pixels(C, esize)); }
 
-// workspace `partial`: Kc * nchunk * C * 2 floats.
+// workspace `partial`: Kc * nchunk * C * 2 floats (pre_nchunk > 0: input, see pcbn_forward_t).
 BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* gamma, const float* beta, int Kc,
                                    int P, int C, float eps, int relu, float* partial, float* mean, float* invstd,
                                    float* scale, float* shift, void* y, void* relu_mask, int esize, int gstride,
-                                   hipStream_t st) {
+                                   int pre_nchunk, hipStream_t st) {
   if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
   if (esize == 4)
     return pcbn_forward_t<float>(x, res, gamma, beta, gstride, Kc, P, C, eps, relu, partial, mean, invstd, scale, shift, y,
-                                 relu_mask, st);
+                                 relu_mask, pre_nchunk, st);
   if (esize == 2)
     return pcbn_forward_t<unsigned short>(x, res, gamma, beta, gstride, Kc, P, C, eps, relu, partial, mean, invstd, scale,
-                                          shift, y, relu_mask, st);
+                                          shift, y, relu_mask, pre_nchunk, st);
   return 2;
 }
 

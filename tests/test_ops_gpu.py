@@ -712,3 +712,50 @@ def test_shuffle_keys_match_oracle(dev):
     got = ops.shuffle_keys(uids, ep, lens, 100, 987654321987)
     want = ref.shuffle_keys(uids.cpu(), ep.cpu(), lens.cpu(), 100, 987654321987)
     assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("Kc,B,Ci,HW,Co,k,s,p", [
+    (3, 8, 64, 32, 64, 3, 1, 1),     # one image per tile
+    (2, 8, 64, 32, 128, 3, 2, 1),    # strided: parity-class segments
+    (3, 8, 128, 8, 256, 3, 1, 1),    # four images per tile
+    (2, 16, 256, 8, 512, 3, 2, 1),   # 4x4 outputs: sixteen images per tile
+    (2, 8, 64, 32, 128, 1, 2, 0),    # shortcut convolution
+    (5, 4, 3, 32, 64, 3, 1, 1),      # stem
+    (2, 8, 32, 40, 48, 3, 1, 1),     # row bands of one image, channel counts that are no multiples of 64
+])
+def test_conv_epilogue_batchnorm_statistics(dev, Kc, B, Ci, HW, Co, k, s, p):
+    """The forward convolution's epilogue sums its output per (client, tile, channel); those partial sums must be
+    the statistics of the stored output, and the per-client BatchNorm fed with them must give what it computes
+    from its own statistics pass (reference: BatchNorm2d over one client's batch,
+    fllib/models/cifar10/resnet_cifar.py:14-30)."""
+    from blades_amd.ops import _hip as h
+
+    torch.manual_seed(1)
+    x = torch.randn(Kc * B, Ci, HW, HW, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Co, Ci, k, k, device=dev) / (Ci * k * k) ** 0.5
+    y, pre = h.conv_forward(x, w, None, s, p, 3, stats_B=B)
+    y0 = h.conv_forward(x, w, None, s, p, 3)
+    assert torch.equal(y, y0)
+    assert pre is not None
+    partial, nch = pre
+    got = partial.view(Kc, nch, Co, 2).double().sum(dim=1)
+    yc = y.permute(0, 2, 3, 1).reshape(Kc, -1, Co).double()
+    torch.testing.assert_close(got[..., 0], yc.sum(dim=1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(got[..., 1], (yc * yc).sum(dim=1), rtol=1e-5, atol=1e-3)
+    if Co % 8 == 0 and 256 % (Co // 8) == 0:
+        gamma, beta = torch.rand(Co, device=dev) + 0.5, torch.randn(Co, device=dev)
+        a = h.pcbn_forward(y, None, gamma, beta, Kc, 1e-5, True, want_mask=True)
+        b = h.pcbn_forward(y, None, gamma, beta, Kc, 1e-5, True, want_mask=True, pre_stats=pre)
+        for u, v in zip(a[:3], b[:3]):
+            torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-5)
+
+
+def test_conv_epilogue_statistics_decline_straddling_tiles(dev):
+    """Three images per client, sixteen per tile: a tile would mix clients, so no statistics are offered."""
+    from blades_amd.ops import _hip as h
+
+    x = torch.randn(6, 64, 4, 4, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 64, 3, 3, device=dev) / 24
+    y, pre = h.conv_forward(x, w, None, 1, 1, 3, stats_B=3)
+    assert pre is None
+    torch.testing.assert_close(y, torch.nn.functional.conv2d(x, w, None, 1, 1), rtol=1e-4, atol=1e-4)
