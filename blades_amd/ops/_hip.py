@@ -583,7 +583,7 @@ def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
         nlines *= 2
     # slots per line: padded width (+3 so the last quad of a ragged row stays inside the line),
     # made = 4 (mod 8) so lines sit 128 B (mod 256 B) apart -> adjacent-row quads do not bank-conflict
-    need = W + 2 * pad + 3
+    need = W + 2 * pad + (3 if W % 4 else 0)
     if stride == 2:
         need = 2 * (-(-(W + 2 * pad) // 2) + 2)
     wslots = need
@@ -675,12 +675,16 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
         plan = _wgrad_plan(B, Ho, Wo, Ho, Wo, 3, 1, 1, x.device)
         if plan["passes"] > 1:
             return False
-        tmt = 4
+        # 128 output channels per workgroup where they exist (conv_wgrad8m_kernel): a class has a quarter of a
+        # stride-1 layer's matrix work per staged step, the wider tile doubles it (BLADES_WGRAD_S2_TMT=4: 64)
+        tmt = 8 if _os.environ.get("BLADES_WGRAD_S2_TMT", "8") == "8" else 4
         while tmt > 1 and Cout % (tmt * 16):
             tmt //= 2
         blocks = 4 * Kc * (Cout // (tmt * 16)) * (-(-Cin // 64))
         slots, bw = 256, 4e12
         t_step = (3.2e-6 if npl == 3 else 1.8e-6) * 0.45  # 9/4 taps per block on average + per-step overhead
+        if tmt == 8:
+            t_step *= 1.4
         best, split = None, 1
         for sp in range(1, max(1, min(16, plan["nsteps"] // 16)) + 1):
             waves = -(-blocks * sp // slots)

@@ -936,6 +936,327 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad8_kernel(const WgradParams p
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// The parity classes of a stride-2 3x3 layer (the MASKED problems above) on 128 output channels per workgroup.
+// A class owns 1, 2 or 4 of the nine taps, so per staged K-step it has a quarter of a stride-1 layer's matrix work
+// and the steps are staging- and barrier-bound.  Doubling the output-channel tile doubles the MFMAs per step at the
+// same x staging and halves the number of workgroup-steps; the accumulators still fit because only the 2 x 2 taps a
+// class can own are kept (view rows oh - 1, oh  x  view columns ow - 1, ow).
+// Staging: every thread carries one 32-byte gy item (32 pixels x 16 eight-channel groups) and one 16-byte x item
+// (32 pixels x 16 four-channel groups): three loads per thread and step.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int NPL>
+__device__ __forceinline__ void split4(const u32x4 v, u32x2 (&pl)[NPL]) {
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  float r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = __uint_as_float(v[j]);
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v{r[2 * j], r[2 * j + 1]}), bf16x2v));
+      pl[q][j] = u;
+      if (q + 1 < NPL) {
+        r[2 * j] -= __uint_as_float(u << 16);
+        r[2 * j + 1] -= __uint_as_float(u & 0xffff0000u);
+      }
+    }
+  }
+}
+
+template <int NPL>
+__global__ __launch_bounds__(512, 1) void conv_wgrad8m_kernel(const WgradParams p) {
+  static_assert(NPL >= 2, "fp32 planes");
+  constexpr int TMT = 8, KV = 2, TV = KV * KV, TAPS = 9, NPF = 3, LPS = 3, MH = TMT / 2;
+  using elem_t = float;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cib = wave & 3, half = wave >> 2;
+  const int per_xcd = gridDim.x >> 3;
+  const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (lid >= p.total_blocks) return;
+  const int n_ci_tiles = (p.Cin + 63) >> 6;
+  const int tile = lid % p.ntiles, rest = lid / p.ntiles;
+  const int c = rest % p.Kc, zsplit = rest / p.Kc;
+  const int n_cls_tiles = 4 * n_ci_tiles;
+  const int co0 = (tile / n_cls_tiles) * (TMT * 16);
+  const int cls = (tile % n_cls_tiles) / n_ci_tiles;
+  const int ci0 = ((tile % n_cls_tiles) % n_ci_tiles) * 64;
+  const int rp = cls >> 1, cp = cls & 1;
+  // view tap (r, sx), r, sx in {0, 1}: input pixel (2 (oh - 1 + r) + rp, 2 (ow - 1 + sx) + cp) = filter tap
+  // (2 r + rp - 1, 2 sx + cp - 1): row 0 exists only in the odd-row classes, column 0 only in the odd-column ones
+  const int tap_mask = (rp ? 3 : 0) | (3 << 2);               // bit r * 2 + sx, before the column mask
+  const int col_mask = cp ? 0xf : 0xa;                        // sx = 0 only with cp
+  const int live = tap_mask & col_mask;
+  auto tap_dst = [&](int t) {
+    const int r = t >> 1, sx = t & 1;
+    return (rp ? 2 * r : 1) * 3 + (cp ? 2 * sx : 1);
+  };
+  constexpr int GYM = 1024 + 32;
+  constexpr int GYB = TMT * GYM;
+  unsigned char* gy_lds = smem;
+  unsigned char* x_lds = smem + 2 * NPL * GYB;
+  const int plane_bytes = (p.nlines + 1) * p.wslots * 32 + 32;
+  const int xpl_bytes = 4 * plane_bytes;
+  const int line_mask = p.nlines - 1;
+  for (int i = tid * 16; i < NPL * xpl_bytes; i += 512 * 16) *reinterpret_cast<u32x4*>(x_lds + i) = u32x4{0, 0, 0, 0};
+
+  const elem_t* xc = reinterpret_cast<const elem_t*>(p.x) + (size_t)c * p.x_client_stride +
+                     (size_t)(rp * (p.rmul >> 1) + cp) * p.Cin;
+  const elem_t* gc = reinterpret_cast<const elem_t*>(p.gy) + (size_t)c * p.B * p.Ho * p.Wo * p.Cout;
+
+  // staging roles of the K loop: thread -> (pixel tid >> 4, group tid & 15) of both operands
+  const int grp16 = tid & 15, pix = tid >> 4;
+  const bool gy_lane = (co0 + grp16 * 8) < p.Cout;
+  const bool x_lane = (ci0 + grp16 * 4) < p.Cin;
+  struct Item { u32x4 g[2]; u32x4 x; };
+  const __attribute__((address_space(4))) int* tbl = (const __attribute__((address_space(4))) int*)(p.table);
+  const elem_t* zeros16 = reinterpret_cast<const elem_t*>(p.table + (size_t)p.nsteps * TBL);
+  auto row_hi = [&](int s) { const int v = (s + 1) * p.rows_r + p.rows_off; return v < p.rows_last ? v : p.rows_last; };
+  auto row_lo = [&](int s) { const int v = s * p.rows_r + p.rows_off; return (v < p.rows_last ? v : p.rows_last) + 1; };
+  auto issue = [&](int s) {
+    const elem_t* ag = zeros16;
+    const int gpix = s * 32 + pix;
+    if (gy_lane && gpix < p.nquads * 4) ag = gc + (size_t)gpix * p.Cout + co0 + grp16 * 8;
+    const elem_t* ax = zeros16;
+    const int lo = row_lo(s), npix = (row_hi(s) - lo + 1) * p.W;
+    if (x_lane && pix < npix) {
+      const int er = pix >> p.w_shift;
+      const size_t pixel = (size_t)(lo + er) * p.rmul + (size_t)(pix - er * p.W) * p.cmul;
+      ax = xc + pixel * p.Cin + ci0 + grp16 * 4;
+    }
+    Item it;
+    it.g[0] = gload16_untracked(ag);
+    it.g[1] = gload16_untracked(reinterpret_cast<const unsigned char*>(ag) + 16);
+    it.x = gload16_untracked(ax);
+    return it;
+  };
+  auto put_gy = [&](int s, const u32x4 lo, const u32x4 hi) {
+    u32x4 pl[NPL];
+    split8<NPL>(lo, hi, pl);
+    unsigned char* dst = gy_lds + (s & 1) * NPL * GYB + (grp16 >> 1) * GYM + pix * 32 + (grp16 & 1) * 16;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(dst + q * GYB) = pl[q];
+  };
+  auto commit = [&](int s, const Item& it) {
+    put_gy(s, it.g[0], it.g[1]);
+    const int lo = row_lo(s), npix = (row_hi(s) - lo + 1) * p.W;
+    if (pix < npix) {
+      const int er = pix >> p.w_shift;
+      const int row = lo + er, iw = pix - er * p.W + p.pad;
+      u32x2 pl[NPL];
+      split4<NPL>(it.x, pl);
+      unsigned char* dst = x_lds + (grp16 >> 2) * plane_bytes + ((row & line_mask) * p.wslots + iw) * 32 + (grp16 & 3) * 8;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(dst + q * xpl_bytes) = pl[q];
+    }
+  };
+
+  f32x4 acc[MH][TV];
+#pragma unroll
+  for (int m = 0; m < MH; ++m)
+#pragma unroll
+    for (int t = 0; t < TV; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool wave_active = (ci0 + cib * 16) < p.Cin;
+  const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+  const unsigned char* x_plane = x_lds + cib * plane_bytes + lq * 32 + lp * 8;
+  const int per = (p.nsteps + p.split - 1) / p.split;
+  const int blk_begin = zsplit * per;
+  const int blk_end = blk_begin + per < p.nsteps ? blk_begin + per : p.nsteps;
+  int s_begin = 0, s_end = 0;
+  __syncthreads();  // zero fill done
+
+  Item stg[NPF];
+  auto compute = [&](int s, auto&& mid) {
+    if (!wave_active) { mid(0); mid(1); return; }
+    int gi0[2], ih0[2], ow0[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int Q = s * 8 + 4 * t + g;
+      const int qx = Q & ((1 << p.lg_qpr) - 1);
+      const int oh = (Q >> p.lg_qpr) & ((1 << p.lg_ho) - 1);
+      const int b = Q >> (p.lg_qpr + p.lg_ho);
+      ow0[t] = qx * 4;
+      ih0[t] = Q < p.nquads ? oh - p.pad : -1000000;
+      gi0[t] = b * p.H + oh - p.pad;
+    }
+    const unsigned char* gy_buf = gy_lds + (s & 1) * NPL * GYB + lq * 32 + lp * 8;
+    const unsigned char* bp[KV][2];
+#pragma unroll
+    for (int r = 0; r < KV; ++r)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ih = ih0[t] + r;
+        const int line = ((unsigned)ih < (unsigned)p.H) ? ((gi0[t] + r) & line_mask) : p.nlines;
+        bp[r][t] = x_plane + (line * p.wslots + ow0[t]) * 32;
+      }
+    i32x4 a[NPL][MH];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q)
+#pragma unroll
+      for (int m = 0; m < MH; ++m) {
+        const unsigned char* gb = gy_buf + q * GYB + (half * MH + m) * GYM;
+        const i32x2 lo = tr_read(gb + (0 * 16 + g * 4) * 32), hi = tr_read(gb + (1 * 16 + g * 4) * 32);
+        a[q][m] = i32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+#pragma unroll
+    for (int r = 0; r < KV; ++r) {
+      if ((live >> (r * KV)) & 3) {  // block-uniform
+        i32x2 hb[NPL][KV * 2];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q)
+#pragma unroll
+          for (int sx = 0; sx < KV; ++sx)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) hb[q][sx * 2 + t] = tr_read(bp[r][t] + q * xpl_bytes + sx * 32);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sx = 0; sx < KV; ++sx) {
+          if (!((live >> (r * KV + sx)) & 1)) continue;  // block-uniform
+          bf16x8 b[NPL];
+#pragma unroll
+          for (int q = 0; q < NPL; ++q) {
+            const i32x2 h0 = hb[q][sx * 2 + 0], h1 = hb[q][sx * 2 + 1];
+            b[q] = __builtin_bit_cast(bf16x8, i32x4{h0[0], h0[1], h1[0], h1[1]});
+          }
+#pragma unroll
+          for (int m = 0; m < MH; ++m) {
+            f32x4 d = acc[m][r * KV + sx];
+            if constexpr (NPL == 3) {
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1][m]), b[1], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]), b[2], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[2][m]), b[0], d, 0, 0, 0);
+            }
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]), b[1], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1][m]), b[0], d, 0, 0, 0);
+            acc[m][r * KV + sx] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]), b[0], d, 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mid(r);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  const int grp = __builtin_amdgcn_readfirstlane(half);
+  const bool ab_stage = (p.ablate & 1) != 0, ab_mfma = (p.ablate & 2) != 0;  // diagnostics (BLADES_WGRAD_ABLATE)
+  auto step = [&](int s, Item& slot_far, const Item& slot_next) {
+    // Unconditional: every thread issues exactly LPS loads per step, so "step s + 1 has landed" is always the same
+    // count, and the staging registers carry no conditional assignment (the compiler resolves those with register
+    // copies, and a copy of a register whose load is still in flight reads garbage).  Steps past the range load
+    // valid memory (or the zero line) that is never committed.
+    slot_far = issue(s + NPF);
+    // the staging commit of the next step: one wave group after the first view row, the other after the second
+    auto stage_next = [&](int r) {
+      if (r != grp) return;
+      wait_vmcnt<(NPF - 1) * LPS>();
+      if (s + 1 < s_end && !ab_stage) commit(s + 1, slot_next);
+    };
+    if (!ab_mfma) compute(s, stage_next);
+    else { stage_next(0); stage_next(1); }
+    __syncthreads();
+  };
+
+  const int nblk_steps = blk_end - blk_begin;
+  const int rot = nblk_steps > 1 ? (int)(((unsigned)c * 7919u + (unsigned)zsplit * 104729u) % (unsigned)nblk_steps) : 0;
+  for (int seg = 0; seg < 2; ++seg) {
+    s_begin = seg == 0 ? blk_begin + rot : blk_begin;
+    s_end = seg == 0 ? blk_end : blk_begin + rot;
+    if (s_begin >= s_end) continue;
+    {
+      // prologue: the whole row window of the first step and its gy tile, synchronously
+      const __attribute__((address_space(4))) int* T = tbl + (size_t)s_begin * TBL;
+      const int w_lo = T[34], w_hi = T[33];
+      const int npix = (w_hi - w_lo + 1) * p.W;
+      for (int e = pix; e < npix; e += 32) {
+        if (x_lane) {
+          const int er = e >> p.w_shift;
+          const size_t pixel = (size_t)(w_lo + er) * p.rmul + (size_t)(e - er * p.W) * p.cmul;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(xc + pixel * p.Cin + ci0 + grp16 * 4);
+          const int row = w_lo + er, iw = e - er * p.W + p.pad;
+          u32x2 pl[NPL];
+          split4<NPL>(v, pl);
+          unsigned char* dst = x_lds + (grp16 >> 2) * plane_bytes + ((row & line_mask) * p.wslots + iw) * 32 + (grp16 & 3) * 8;
+#pragma unroll
+          for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(dst + q * xpl_bytes) = pl[q];
+        }
+      }
+      u32x4 g0 = u32x4{0, 0, 0, 0}, g1 = u32x4{0, 0, 0, 0};
+      const int gpix = s_begin * 32 + pix;
+      if (gy_lane && gpix < p.nquads * 4) {
+        const elem_t* src = gc + (size_t)gpix * p.Cout + co0 + grp16 * 8;
+        g0 = *reinterpret_cast<const u32x4*>(src);
+        g1 = *reinterpret_cast<const u32x4*>(src + 4);
+      }
+      put_gy(s_begin, g0, g1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < NPF; ++k) stg[k] = issue(s_begin + k);
+    for (int s0 = s_begin; s0 < s_end; s0 += NPF) {
+#pragma unroll
+      for (int k = 0; k < NPF; ++k)
+        if (s0 + k < s_end) step(s0 + k, stg[k], stg[(k + 1) % NPF]);
+    }
+    wait_vmcnt<0>();  // the look-ahead loads past the range: their registers are about to be reused
+  }
+
+  // ---- epilogue: each wave's [MH x 16 co][16 ci x 9 taps] through LDS, lane-contiguous stores of the owned taps ----
+  const bool to_scratch = p.split > 1;
+  const float cf = (p.coef && !to_scratch) ? p.coef[c] : 1.f;
+  float* row = to_scratch ? p.scratch + ((size_t)zsplit * p.Kc + c) * p.numel : p.U + (size_t)c * p.ld + p.off;
+  const bool accum = p.accumulate && !to_scratch;
+  constexpr int SEG = 16 * TAPS, SEGP = SEG + 4;
+  const bool full_tile = (p.Cs == p.Cin) && (ci0 + 64 <= p.Cin);  // block-uniform
+  if (full_tile) {
+    float* tile_l = reinterpret_cast<float*>(smem) + wave * 16 * SEGP;
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < TV; ++t)
+          if ((live >> t) & 1) tile_l[(g * 4 + q) * SEGP + li * TAPS + tap_dst(t)] = cf * acc[m][t][q];
+      __syncthreads();
+      float* dst0 = row + ((size_t)(co0 + (half * MH + m) * 16) * p.Cin + ci0 + cib * 16) * TAPS;
+#pragma unroll
+      for (int j = 0; j < 16 * SEG / 64; ++j) {
+        const int f = j * 64 + lane;
+        const int r = f / SEG, col = f - r * SEG;
+        float* d = dst0 + (size_t)r * p.Cin * TAPS + col;
+        const float v = tile_l[r * SEGP + col];
+        const int k = col % TAPS, kr = k / 3, kc = k - kr * 3;
+        if ((kr == 1) == (rp == 0) && (kc == 1) == (cp == 0)) *d = accum ? *d + v : v;
+      }
+    }
+    return;
+  }
+  if (wave_active) {
+    const int ci = ci0 + cib * 16 + li;
+#pragma unroll
+    for (int m = 0; m < MH; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = co0 + (half * MH + m) * 16 + g * 4 + q;
+        if (co < p.Cout && ci < p.Cs) {
+          float* dst = row + ((size_t)co * p.Cs + ci) * TAPS;
+#pragma unroll
+          for (int t = 0; t < TV; ++t)
+            if ((live >> t) & 1) {
+              const float v = cf * acc[m][t][q];
+              float* d = dst + tap_dst(t);
+              *d = accum ? *d + v : v;
+            }
+        }
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ scratch, int split, int Kc,
                                                            long numel, const float* __restrict__ coef,
                                                            float* __restrict__ U, long ld, long off, int accumulate) {
@@ -994,6 +1315,34 @@ int launch8(const WgradParams& p, int Kc, hipStream_t st) {
   q.total_blocks = q.ntiles * Kc * p.split;
   const int grid = (q.total_blocks + 7) / 8 * 8;
   hipLaunchKernelGGL((conv_wgrad8_kernel<TMT, NPL, MASKED>), dim3(grid), dim3(512), lds, st, q);
+  if (p.split > 1) {
+    int gx = cdiv(p.numel, 256 * 4);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, Kc), dim3(256), 0, st, p.scratch, p.split, Kc, p.numel, p.coef,
+                       p.U, p.ld, p.off, p.accumulate);
+  }
+  return 0;
+}
+
+template <int NPL>
+int launch8m(const WgradParams& p, int Kc, hipStream_t st) {
+  constexpr int TMT = 8;
+  size_t lds = NPL * (2 * TMT * (1024 + 32) + 4 * ((size_t)(p.nlines + 1) * p.wslots * 32 + 32));
+  const size_t lds_epilogue = 8 * 16 * (16 * 9 + 4) * sizeof(float);
+  if (lds < lds_epilogue) lds = lds_epilogue;
+  if (lds > 160 * 1024) return 3;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad8m_kernel<NPL>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int n_ci_tiles = (p.Cin + 63) / 64, n_co_tiles = p.Cout / (TMT * 16);
+  WgradParams q = p;
+  q.ntiles = n_co_tiles * n_ci_tiles * 4;
+  q.total_blocks = q.ntiles * Kc * p.split;
+  const int grid = (q.total_blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL((conv_wgrad8m_kernel<NPL>), dim3(grid), dim3(512), lds, st, q);
   if (p.split > 1) {
     int gx = cdiv(p.numel, 256 * 4);
     if (gx > 1024) gx = 1024;
@@ -1069,6 +1418,11 @@ BLADES_API int blades_conv_wgrad(const void* x, const void* gy, float* U, long l
     if (npl == 2) return launch8<T, 2, M>(p, Kc, st);          \
     return launch8<T, 3, M>(p, Kc, st);                        \
   } while (0)
+    if (masked && tmt == 8) {  // 128 output channels per workgroup
+      const int rc = npl == 2 ? launch8m<2>(p, Kc, st) : launch8m<3>(p, Kc, st);
+      if (rc != 3) return rc;
+      tmt = 4;  // the plane images do not fit next to a 128-channel gy tile: 64-channel tiles
+    }
     if (masked) { if (tmt == 4) GO8(4, true); GO8(2, true); }
     if (tmt == 4) GO8(4, false);
     GO8(2, false);

@@ -21,11 +21,11 @@ def main():
                               stderr=subprocess.DEVNULL)
         text = open(out).read()
     bad = 0
-    for m in re.finditer(r"\.name:\s+(\S*conv_wgrad8?_kernel\S*)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
+    for m in re.finditer(r"\.name:\s+(\S*conv_wgrad8?m?_kernel\S*)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
         name, spills = m.group(1), int(m.group(2))
         # FAST variants of the four-wave kernel (template argument 5 = true) and every eight-wave variant keep
         # untracked loads in flight in registers
-        fast = "conv_wgrad8_kernel" in name or re.search(r"ELb1ELi\dELb[01]EEEvNS_11WgradParamsE$", name) is not None
+        fast = "conv_wgrad8_kernel" in name or "conv_wgrad8m_kernel" in name or re.search(r"ELb1ELi\dELb[01]EEEvNS_11WgradParamsE$", name) is not None
         print(f"{'FAST' if fast else 'table'} {name}: {spills} VGPR spills")
         if fast and spills:
             bad += 1
