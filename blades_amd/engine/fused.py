@@ -84,6 +84,18 @@ _DGRAD_AS_FWD = _os.environ.get("BLADES_DGRAD_AS_FWD", "1") != "0"
 _CONV_IMPL = _os.environ.get("BLADES_CONV_IMPL", "hip").lower()
 # BatchNorm statistics from the convolution kernel's epilogue (0: separate statistics pass, for A/B runs)
 _BN_STATS_IN_CONV = _os.environ.get("BLADES_BN_STATS_IN_CONV", "1") != "0"
+# first-layer 3x3 convolution as a 1x1 convolution over an im2col tensor (0: padded 3-channel implicit GEMM)
+_STEM_IM2COL = _os.environ.get("BLADES_STEM_IM2COL", "1") != "0"
+
+
+def _stem_im2col(x: torch.Tensor, k: int, pad: int) -> torch.Tensor:
+    """[N, Ci, H, W] -> [N, 32, H, W] (channels-last storage), channel ci*k*k + r*k + s = x[ci, h + r - pad,
+    w + s - pad], zero beyond Ci*k*k: the row order of ``weight.reshape(Co, Ci*k*k)``."""
+    N, Ci, H, W = x.shape
+    cols = F.unfold(x, k, padding=pad)  # [N, Ci*k*k, H*W]
+    out = x.new_zeros((N, H * W, 32))
+    out[:, :, : Ci * k * k] = cols.transpose(1, 2)
+    return out.view(N, H, W, 32).permute(0, 3, 1, 2)
 
 
 def _own_conv(x, mod) -> bool:
@@ -122,6 +134,24 @@ class _PCConvFn(torch.autograd.Function):
             w = w.contiguous(memory_format=torch.channels_last)
         ctx.mod = mod
         ctx.own = _own_conv(x, mod)
+        ctx.stem = False
+        Ci, kh, kw = int(weight.shape[-3]), int(weight.shape[-2]), int(weight.shape[-1])
+        if (ctx.own and _STEM_IM2COL and mod.sink.npl > 1 and not x.requires_grad and Ci <= 3 and kh == kw == 3
+                and list(mod.stride) == [1, 1] and list(mod.padding) == [1, 1] and mod.sink.Kc
+                and x.shape[0] % mod.sink.Kc == 0):
+            # Stem: K = 27 of the 9 x 32 padded channels of the implicit GEMM are real.  As a 1x1 convolution over
+            # the im2col tensor the forward pass is one K-step instead of nine and the weight gradient a plain
+            # [pixels x 64]^T [pixels x 32] GEMM (a quarter of the MFMAs), for one extra 128-byte-per-pixel tensor.
+            col = _stem_im2col(x, 3, 1)
+            wk = mod.sink.param(weight).detach()
+            w2 = F.pad(wk.reshape(*wk.shape[:-3], Ci * 9), (0, 32 - Ci * 9)).reshape(*wk.shape[:-3], 32, 1, 1)
+            ctx.stem = True
+            ctx.save_for_backward(col, w2)
+            if want_stats and _BN_STATS_IN_CONV:
+                y, mod.bn_stats = _hipmod().conv_forward(col, w2, mod.sink.param(mod.bias), 1, 0, mod.sink.npl,
+                                                         stats_B=x.shape[0] // mod.sink.Kc)
+                return y
+            return _hipmod().conv_forward(col, w2, mod.sink.param(mod.bias), 1, 0, mod.sink.npl)
         if ctx.own:
             # hand-written implicit-GEMM kernel; reads the fp32 master weights itself (split into bf16 planes) —
             # the shared ones, or each client's own set when the sink carries per-client weights
@@ -148,6 +178,18 @@ class _PCConvFn(torch.autograd.Function):
         Kc, B = sink.Kc, sink.B
         gy = gy.contiguous(memory_format=torch.channels_last) if gy.dim() == 4 else gy
         dx = None
+        if ctx.stem:
+            off, _ = sink.offsets[id(mod.weight)]
+            acc = id(mod.weight) in sink._written
+            ok = _hipmod().conv_wgrad_(x, gy, Kc, sink.block, off, sink.scale, acc, 1, 1, 0, sink.npl,
+                                       cin_store=int(mod.weight.shape[1]) * 9)
+            if not ok:
+                raise RuntimeError("stem weight gradient: the 1x1 kernel rejected the im2col problem")
+            sink._written.add(id(mod.weight))
+            if mod.bias is not None:
+                g = gy.permute(0, 2, 3, 1)
+                sink.write(mod.bias, g.reshape(Kc, -1, gy.shape[1]).sum(dim=1, dtype=torch.float32))
+            return None, None, None, None
         if ctx.needs_input_grad[0] and ctx.own:
             dx = _hipmod().conv_dgrad(gy, w, (int(x.shape[2]), int(x.shape[3])), int(mod.stride[0]),
                                       int(mod.padding[0]), sink.npl)

@@ -638,10 +638,11 @@ def conv_wgrad_supported(x, gy, ks, stride, pad, dilation) -> bool:
 
 
 def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: int, stride: int, pad: int,
-                npl: int = 0):
+                npl: int = 0, cin_store: int = 0):
     """Writes coef[c] * dW_c into U_block[c, off : off + Cout*Cin*ks*ks] for every client c.
     bf16 activations run as they are; fp32 activations are split in-kernel into ``npl`` bf16 planes
-    (3 = fp32 grade, 2 = "bf16x3")."""
+    (3 = fp32 grade, 2 = "bf16x3").  ``cin_store`` < Cin: ``x`` carries zero-padded channels; only the first
+    ``cin_store`` input channels are stored (row layout ``[Cout][cin_store][ks][ks]``)."""
     if x.dtype == torch.bfloat16:
         npl = 1
     elif npl not in (2, 3):
@@ -656,11 +657,13 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
     if Ho != (H + 2 * pad - ks) // stride + 1 or Wo != (W + 2 * pad - ks) // stride + 1:
         raise ValueError("conv_wgrad_: output size does not match the convolution geometry")
     K, Dl, ld = _chk_matrix(U_block)
-    numel = Cout * Cin * ks * ks
+    if cin_store and not (0 < cin_store <= Cin and Cin % 16 == 0):
+        raise ValueError("conv_wgrad_: cin_store needs an input padded to a multiple of 16 channels")
+    cin_store = cin_store or Cin
+    numel = Cout * cin_store * ks * ks
     if K != Kc or off < 0 or off + numel > Dl:
         raise ValueError("conv_wgrad_: update-matrix block does not match")
     coef = _vec(coef, Kc, x.device, name="coef")
-    cin_store = Cin
     if Cin % 16:
         # the stem (3 input channels): zero-pad to one 16-channel MFMA block; only the real channels are stored
         xp = x.new_zeros((N, H, W, 16)).permute(0, 3, 1, 2)  # channels-last storage
