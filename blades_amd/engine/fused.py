@@ -92,6 +92,8 @@ def _stem_im2col(x: torch.Tensor, k: int, pad: int) -> torch.Tensor:
     """[N, Ci, H, W] -> [N, 32, H, W] (channels-last storage), channel ci*k*k + r*k + s = x[ci, h + r - pad,
     w + s - pad], zero beyond Ci*k*k: the row order of ``weight.reshape(Co, Ci*k*k)``."""
     N, Ci, H, W = x.shape
+    if x.is_cuda and x.dtype == torch.float32:
+        return _hipmod().stem_im2col(x, k, pad)  # ops/csrc/im2col.hip
     cols = F.unfold(x, k, padding=pad)  # [N, Ci*k*k, H*W]
     out = x.new_zeros((N, H * W, 32))
     out[:, :, : Ci * k * k] = cols.transpose(1, 2)

@@ -960,6 +960,20 @@ def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, 
     return (partial, nch) if partial is not None else None
 
 
+_stem_im2col_c = _sig("blades_stem_im2col", [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int)
+
+
+def stem_im2col(x: torch.Tensor, k: int, pad: int) -> torch.Tensor:
+    """fp32 channels-last ``[N, Ci, H, W]`` (``Ci*k*k <= 32``) -> ``[N, 32, H, W]`` channels-last with channel
+    ``ci*k*k + r*k + s`` = the input under tap ``(r, s)`` (zero padding, zero beyond ``Ci*k*k``)."""
+    _chk_nhwc(x, "x", torch.float32)
+    N, Ci, H, W = x.shape
+    out = _empty((N, 32, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if _stem_im2col_c(_ptr(x), _ptr(out), N, H, W, Ci, int(k), int(pad), _stream()) != 0:
+        raise ValueError(f"stem_im2col: unsupported shape Ci={Ci} k={k}")
+    return out
+
+
 def conv_forward(x, weight, bias, stride: int, pad: int, npl: int, stats_B: int = 0):
     """y = conv2d(x, weight, bias) for channels-last x; fp32 (npl 3 / 2) or bf16 (npl 1) in and out.
     ``stats_B`` > 0 (fp32 tensors, ``stats_B`` images per client): returns ``(y, pre_stats)`` where ``pre_stats`` is

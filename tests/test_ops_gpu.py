@@ -759,3 +759,33 @@ def test_conv_epilogue_statistics_decline_straddling_tiles(dev):
     y, pre = h.conv_forward(x, w, None, 1, 1, 3, stats_B=3)
     assert pre is None
     torch.testing.assert_close(y, torch.nn.functional.conv2d(x, w, None, 1, 1), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("npl", [3, 2])
+def test_stem_as_im2col_pointwise_convolution(dev, npl):
+    """The engine runs a 3-channel 3x3 stem as a 1x1 convolution over an im2col tensor (27 real of 32 channels):
+    forward and per-client weight gradient (``cin_store`` = 27, rows laid out as [Co][Ci][3][3]) against torch."""
+    import torch.nn.functional as F
+    from blades_amd.engine.fused import _stem_im2col
+    from blades_amd.ops import _hip as h
+
+    torch.manual_seed(3)
+    Kc, B, Co = 3, 4, 64
+    x = torch.randn(Kc * B, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Co, 3, 3, 3, device=dev) / 5
+    gy = torch.randn(Kc * B, Co, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    col = _stem_im2col(x, 3, 1)
+    assert col.shape == (Kc * B, 32, 32, 32) and col.is_contiguous(memory_format=torch.channels_last)
+    w2 = F.pad(w.reshape(Co, 27), (0, 5)).reshape(Co, 32, 1, 1)
+    y = h.conv_forward(col, w2, None, 1, 0, npl)
+    tol = 2e-5 if npl == 3 else 2e-3
+    torch.testing.assert_close(y, F.conv2d(x, w, None, 1, 1), rtol=tol, atol=tol)
+    U = torch.full((Kc, Co * 27 + 9), 7.0, device=dev)
+    coef = torch.tensor([1.0, -0.5, 2.0], device=dev)
+    assert h.conv_wgrad_(col, gy, Kc, U, 4, coef, False, 1, 1, 0, npl, cin_store=27)
+    ref = torch.stack([torch.ops.aten.convolution_backward(gy[c * B:(c + 1) * B], x[c * B:(c + 1) * B], w, None, [1, 1],
+                                                           [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+                       * coef[c] for c in range(Kc)])
+    got = U[:, 4:4 + Co * 27].reshape(Kc, Co, 3, 3, 3)
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol * float(ref.abs().max()))
+    assert float((U[:, :4] - 7).abs().max()) == 0 and float((U[:, 4 + Co * 27:] - 7).abs().max()) == 0
