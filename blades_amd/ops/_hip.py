@@ -23,7 +23,9 @@ if not _build.HIP_LIB.exists():
         "(hipcc cross-compiles gfx950 without a GPU). GPU tensors have no other implementation."
     )
 
-_lib = ctypes.CDLL(str(_build.HIP_LIB))
+# BLADES_HIP_LIB: another build of the same sources' ABI (same-box A/B runs of kernel changes)
+_lib = ctypes.CDLL(_os_environ_lib) if (_os_environ_lib := __import__("os").environ.get("BLADES_HIP_LIB")) else \
+    ctypes.CDLL(str(_build.HIP_LIB))
 
 _P = c_void_p
 
@@ -583,7 +585,7 @@ def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
         nlines *= 2
     # slots per line: padded width (+3 so the last quad of a ragged row stays inside the line),
     # made = 4 (mod 8) so lines sit 128 B (mod 256 B) apart -> adjacent-row quads do not bank-conflict
-    need = W + 2 * pad + (3 if W % 4 else 0)
+    need = W + 2 * pad + (3 if (W % 4 or _os.environ.get("BLADES_WGRAD_LINEPAD") == "3") else 0)
     if stride == 2:
         need = 2 * (-(-(W + 2 * pad) // 2) + 2)
     wslots = need

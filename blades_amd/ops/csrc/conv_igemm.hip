@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   constexpr int CPL = SPLIT ? 4 : 8, LPP = KC / CPL, PIXPP = 256 / LPP;
   const int cg = tid % LPP, pp = tid / LPP;
   struct ADesc { long goff; int slot; };
-  auto a_desc = [&](int pass, int seg) {
+  auto a_desc = [&](int pass, long seg_goff) {
     ADesc d;
     const int e = pass * PIXPP + pp;
     const int il = fdiv(e, p.inv_irwi), rem = e - il * p.IR * p.Wi;
@@ -160,8 +160,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     const int iy = iy_lo + r;
     const bool ok = e < p.region_px && (unsigned)iy < (unsigned)p.Hi && img0 + il < p.N;
     d.slot = il * p.IS + r * p.WS + ix + p.PL;
-    d.goff = ok ? (((long)(img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci +
-                      p.seg_goff[seg]
+    d.goff = ok ? (((long)(img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci + seg_goff
                 : -1;
     return d;
   };
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     }
   };
   // whole-chunk staging with every load of a batch in flight before the first conversion
-  auto a_stage_sync = [&](int pass_begin, int c0, int seg) {
+  auto a_stage_sync = [&](int pass_begin, int c0, long seg) {
     for (int j0 = pass_begin; j0 < p.npass; j0 += 4) {
       ADesc d[4];
       u32x4 v[4];
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   const int nchunks = p.Cip / KC, nsteps = nchunks * p.ntaps;
   __syncthreads();  // zero fill complete
   if (nsteps > 0) {
-    a_stage_sync(0, 0, 0);
+    a_stage_sync(0, 0, p.seg_goff[0]);
 #pragma unroll
     for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q);
   }
@@ -246,15 +245,24 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
   // (segment, chunk) pair changes
   int g = 0, c = 0, t = 0;
+  long goff_cur = p.seg_goff[0];
+  int toff_cur = p.tap_off[0];  // this step's tap offset, loaded one step ahead (kernel-argument loads have the
+                                // latency of a cache access and share their counter with the LDS reads)
+  int seg_lo = p.seg_begin[0], seg_hi = p.seg_begin[1];  // taps of segment g (kept in registers: a kernel-argument
+                                                         // load per step shows in the short steps of the bf16 kernels)
   for (int ks = 0; ks < nsteps; ++ks) {
     int tn = t + 1, cn = c, gn = g;
-    if (tn == p.seg_begin[g + 1]) {
-      tn = p.seg_begin[g]; cn = c + 1;
-      if (cn == nchunks) { cn = 0; gn = g + 1; tn = p.seg_begin[g + 1]; }
+    if (tn == seg_hi) {
+      tn = seg_lo; cn = c + 1;
+      if (cn == nchunks) { cn = 0; gn = g + 1; tn = seg_hi; }
     }
     const bool more = ks + 1 < nsteps;
     const bool next_b = more && !(p.ablate & 1);
     const bool next_a = more && (cn != c || gn != g) && !(p.ablate & 1);  // this step ends (g, c): restage A after it
+    long goff_next = goff_cur;
+    if (gn != g && more) goff_next = p.seg_goff[gn];
+    const int toff = toff_cur;
+    if (more) toff_cur = p.tap_off[tn];
     // 1. global loads: next step's weight tile; at a chunk's last tap also the next chunk of the input tile.
     //    They complete under this step's MFMAs (and under the MFMAs of the workgroup sharing the CU).
     u32x4 breg[NPL];
@@ -268,13 +276,12 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
 #pragma unroll
       for (int j = 0; j < MAXPF; ++j) {
         areg[j] = u32x4{0, 0, 0, 0};
-        if (j < p.npass) areg[j] = a_load(a_desc(j, gn), cn * KC);
+        if (j < p.npass) areg[j] = a_load(a_desc(j, goff_next), cn * KC);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     // 2. MFMAs of (chunk c, tap t)
     if (!(p.ablate & 4)) {
-      const int toff = p.tap_off[t];
       bf16x8 wf[NPL][4];
 #pragma unroll
       for (int q = 0; q < NPL; ++q)
@@ -313,11 +320,12 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     if (next_a && !(p.ablate & 2)) {
 #pragma unroll
       for (int j = 0; j < MAXPF; ++j)
-        if (j < p.npass) a_store(a_desc(j, gn), areg[j]);
-      a_stage_sync(MAXPF, cn * KC, gn);  // geometries with more than MAXPF passes: the rest without prefetch
+        if (j < p.npass) a_store(a_desc(j, goff_next), areg[j]);
+      a_stage_sync(MAXPF, cn * KC, goff_next);  // geometries with more than MAXPF passes: the rest without prefetch
     }
     __syncthreads();
-    t = tn; c = cn; g = gn;
+    if (gn != g && more) { seg_lo = seg_hi; seg_hi = p.seg_begin[gn + 1]; }
+    t = tn; c = cn; g = gn; goff_cur = goff_next;
   }
 
   // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
