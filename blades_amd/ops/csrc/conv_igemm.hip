@@ -246,8 +246,11 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   // (segment, chunk) pair changes
   int g = 0, c = 0, t = 0;
   long goff_cur = p.seg_goff[0];
-  int toff_cur = p.tap_off[0];  // this step's tap offset, loaded one step ahead (kernel-argument loads have the
-                                // latency of a cache access and share their counter with the LDS reads)
+  // The tap tables live in one register each (lane i holds entry i) and are read with v_readlane: a kernel-argument
+  // load indexed by the step's tap has the latency of a cache access, shares its counter with the LDS reads, and sat
+  // in front of every step's weight prefetch and fragment-read burst.
+  static_assert(MAXTAPS <= 64, "one lane per tap");
+  const int lane_toff = p.tap_off[lane < MAXTAPS ? lane : 0], lane_tw = p.tap_w[lane < MAXTAPS ? lane : 0];
   int seg_lo = p.seg_begin[0], seg_hi = p.seg_begin[1];  // taps of segment g (kept in registers: a kernel-argument
                                                          // load per step shows in the short steps of the bf16 kernels)
   for (int ks = 0; ks < nsteps; ++ks) {
@@ -261,13 +264,12 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     const bool next_a = more && (cn != c || gn != g) && !(p.ablate & 1);  // this step ends (g, c): restage A after it
     long goff_next = goff_cur;
     if (gn != g && more) goff_next = p.seg_goff[gn];
-    const int toff = toff_cur;
-    if (more) toff_cur = p.tap_off[tn];
+    const int toff = __builtin_amdgcn_readlane(lane_toff, t);
     // 1. global loads: next step's weight tile; at a chunk's last tap also the next chunk of the input tile.
     //    They complete under this step's MFMAs (and under the MFMAs of the workgroup sharing the CU).
     u32x4 breg[NPL];
     if (next_b) {
-      const int tw = p.tap_w[tn];
+      const int tw = __builtin_amdgcn_readlane(lane_tw, tn);
 #pragma unroll
       for (int q = 0; q < NPL; ++q) breg[q] = b_load(tw, cn * KC, q);
     }
