@@ -686,7 +686,7 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
         while tmt > 1 and Cout % (tmt * 16):
             tmt //= 2
         blocks = 4 * Kc * (Cout // (tmt * 16)) * (-(-Cin // 64))
-        slots, bw = 256, 4e12
+        slots, bw = int(_os.environ.get("BLADES_WGRAD_SLOTS", 256)), 4e12
         t_step = (3.2e-6 if npl == 3 else 1.8e-6) * 0.45  # 9/4 taps per block on average + per-step overhead
         if tmt == 8:
             t_step *= 1.4
@@ -728,6 +728,7 @@ def conv_wgrad_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks: i
     slots, t_step, bw = 512, 1.5e-6, 4e12
     if npl > 1:  # split planes: one resident block per CU (the plane images fill LDS), 3 / 6 MFMA products per step
         slots, t_step = 256, (3.2e-6 if npl == 3 else 1.8e-6)
+        slots = int(_os.environ.get("BLADES_WGRAD_SLOTS", slots))
     best, split = None, 1
     for sp in range(1, max(1, min(16, plan["nsteps"] // 16)) + 1):
         waves = -(-blocks * sp // slots)
