@@ -23,9 +23,8 @@ if not _build.HIP_LIB.exists():
         "(hipcc cross-compiles gfx950 without a GPU). GPU tensors have no other implementation."
     )
 
-# BLADES_HIP_LIB: another build of the same sources' ABI (same-box A/B runs of kernel changes)
-_lib = ctypes.CDLL(_os_environ_lib) if (_os_environ_lib := __import__("os").environ.get("BLADES_HIP_LIB")) else \
-    ctypes.CDLL(str(_build.HIP_LIB))
+# BLADES_HIP_LIB: another build with the same ABI (same-box A/B runs of kernel changes, tools/ab_lib.sh)
+_lib = ctypes.CDLL(__import__("os").environ.get("BLADES_HIP_LIB") or str(_build.HIP_LIB))
 
 _P = c_void_p
 
