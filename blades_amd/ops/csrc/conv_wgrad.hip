@@ -747,13 +747,18 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad8_kernel(const WgradParams p
           const int line = ((unsigned)ih < (unsigned)p.H) ? ((gi0[t] + r) & line_mask) : p.nlines;
           bp[r][t] = x_plane + (line * p.wslots + ow0[t]) * 32;
         }
-      i32x2 hb[2][NPL][KS * 2];
+      // x fragments of one kernel row.  MASKED: one read per (tap column, quad).  Otherwise the three tap columns are
+      // windows of the same 8 slots: two reads per quad (slots ow0.. and ow0 + 4..) and the middle window by two
+      // v_alignbit — a third less LDS read traffic for the same operands (WIN = reads per quad and row).
+      constexpr int WIN = MASKED ? KS : 2;
+      i32x2 hb[2][NPL][WIN * 2];
 #pragma unroll
       for (int q = 0; q < NPL; ++q)
 #pragma unroll
-        for (int sx = 0; sx < KS; ++sx)
+        for (int sx = 0; sx < WIN; ++sx)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) hb[0][q][sx * 2 + t] = tr_read(bp[0][t] + q * xpl_bytes + sx * 32);
+          for (int t = 0; t < 2; ++t)
+            hb[0][q][sx * 2 + t] = tr_read(bp[0][t] + q * xpl_bytes + sx * (MASKED ? 32 : 128));
       i32x4 a[NPL][MH];
 #pragma unroll
       for (int q = 0; q < NPL; ++q)
@@ -769,10 +774,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad8_kernel(const WgradParams p
 #pragma unroll
           for (int q = 0; q < NPL; ++q)
 #pragma unroll
-            for (int sx = 0; sx < KS; ++sx)
+            for (int sx = 0; sx < WIN; ++sx)
 #pragma unroll
               for (int t = 0; t < 2; ++t)
-                hb[(r + 1) & 1][q][sx * 2 + t] = tr_read(bp[r + 1][t] + q * xpl_bytes + sx * 32);
+                hb[(r + 1) & 1][q][sx * 2 + t] =
+                    tr_read(bp[r + 1][t] + q * xpl_bytes + sx * (MASKED ? 32 : 128));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -781,7 +787,20 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad8_kernel(const WgradParams p
           bf16x8 b[NPL];
 #pragma unroll
           for (int q = 0; q < NPL; ++q) {
-            const i32x2 h0 = hb[r & 1][q][sx * 2 + 0], h1 = hb[r & 1][q][sx * 2 + 1];
+            i32x2 h0, h1;
+            if constexpr (MASKED) {
+              h0 = hb[r & 1][q][sx * 2 + 0]; h1 = hb[r & 1][q][sx * 2 + 1];
+            } else {
+              // quad t: slots ow0 .. ow0 + 3 in A, ow0 + 4 .. ow0 + 7 in B; tap column sx = slots ow0 + sx .. + 3
+              auto window = [&](const i32x2 A, const i32x2 B) {
+                if (sx == 0) return A;
+                if (sx == 2) return i32x2{A[1], B[0]};
+                return i32x2{(int)__builtin_amdgcn_alignbit((unsigned)A[1], (unsigned)A[0], 16),
+                             (int)__builtin_amdgcn_alignbit((unsigned)B[0], (unsigned)A[1], 16)};
+              };
+              h0 = window(hb[r & 1][q][0], hb[r & 1][q][2]);
+              h1 = window(hb[r & 1][q][1], hb[r & 1][q][3]);
+            }
             b[q] = __builtin_bit_cast(bf16x8, i32x4{h0[0], h0[1], h1[0], h1[1]});
           }
 #pragma unroll
