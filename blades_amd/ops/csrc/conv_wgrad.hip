@@ -1126,11 +1126,13 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad8m_kernel(const WgradParams 
       if ((live >> (r * KV)) & 3) {  // block-uniform
         i32x2 hb[NPL][KV * 2];
 #pragma unroll
-        for (int q = 0; q < NPL; ++q)
+        for (int sx = 0; sx < KV; ++sx) {
+          if (!((live >> (r * KV + sx)) & 1)) continue;  // block-uniform: the even-column classes own one column
 #pragma unroll
-          for (int sx = 0; sx < KV; ++sx)
+          for (int q = 0; q < NPL; ++q)
 #pragma unroll
             for (int t = 0; t < 2; ++t) hb[q][sx * 2 + t] = tr_read(bp[r][t] + q * xpl_bytes + sx * 32);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sx = 0; sx < KV; ++sx) {

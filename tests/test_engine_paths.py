@@ -204,3 +204,20 @@ def test_frozen_parameters_take_no_update_columns(data_root, nb):
     if nb == 1:  # sequential clients draw their batches from a DataLoader-like reader with the same sampler
         assert res["sequential"][0].shape == res["vmap"][0].shape
     assert torch.equal(a.engine.task.model.classifier.positional_emb, pe0)
+
+
+def test_stem_im2col_torch_path_matches_convolution():
+    """The engine's im2col of a first-layer input (torch branch; the GPU branch is ops/csrc/im2col.hip): a 1x1
+    convolution over it with ``weight.reshape(Co, Ci*9)`` padded to 32 channels is the 3x3 convolution."""
+    import torch.nn.functional as F
+    from blades_amd.engine.fused import _stem_im2col
+
+    torch.manual_seed(0)
+    for Ci in (1, 3):
+        x = torch.randn(5, Ci, 9, 7)
+        w = torch.randn(6, Ci, 3, 3)
+        col = _stem_im2col(x, 3, 1)
+        assert col.shape == (5, 32, 9, 7)
+        w2 = F.pad(w.reshape(6, Ci * 9), (0, 32 - Ci * 9)).reshape(6, 32, 1, 1)
+        torch.testing.assert_close(F.conv2d(col, w2), F.conv2d(x, w, None, 1, 1), rtol=1e-5, atol=1e-5)
+        assert float(col[:, Ci * 9:].abs().max()) == 0
