@@ -77,6 +77,8 @@ struct IgemmParams {
   int n_clients, imgs_per_client;  // per-client weights (local steps > 1): image n uses weight set n / imgs_per_client
   long wp_client_stride, bias_client_stride;  // elements between two clients' weight planes / biases
   int ablate;                 // diagnostics (BLADES_IGEMM_ABLATE): 1 no staging loads, 2 no commit, 4 no MFMAs
+  int bdouble;                // two weight-tile images in LDS (where they fit): a step's successor tile is committed
+                              // without waiting for the other waves, one barrier per step instead of two
   float* stats;               // forward, fp32 output: per-(client, tile, channel) sum / sum of squares of the
   int stats_B, stats_nchunk;  // output — the first pass of the per-client BatchNorm that follows (pcbn.hip's
                               // partial[(client * nchunk + chunk) * Co + ch][2]); stats_B = images per client
@@ -224,7 +226,10 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     return *reinterpret_cast<const u32x4*>(wp_c + q * w_plane + ((size_t)tw * p.Cop + n0 + brow) * p.Cip + c0 + bkg * 8);
   };
   const int b_dst = brow * 64 + ((bkg * 16) ^ swz(brow));
-  auto b_store = [&](u32x4 v, int q) { *reinterpret_cast<u32x4*>(B_lds + q * b_plane + b_dst) = v; };
+  const int b_img = p.bdouble ? NPL * b_plane : 0;  // distance between the two weight-tile images
+  auto b_store = [&](u32x4 v, int q, int img) {
+    *reinterpret_cast<u32x4*>(B_lds + img * b_img + q * b_plane + b_dst) = v;
+  };
 
   f32x4 acc[MF][4];
 #pragma unroll
@@ -237,11 +242,11 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   if (nsteps > 0) {
     a_stage_sync(0, 0, p.seg_goff[0]);
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q);
+    for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q, 0);
   }
   __syncthreads();
 
-  const unsigned char* Bb = B_lds + li * 64 + ((kg * 16) ^ swz(li));
+  const unsigned char* Bb0 = B_lds + li * 64 + ((kg * 16) ^ swz(li));
   // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
   // (segment, chunk) pair changes
   int g = 0, c = 0, t = 0;
@@ -260,7 +265,8 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
       if (cn == nchunks) { cn = 0; gn = g + 1; tn = seg_hi; }
     }
     const bool more = ks + 1 < nsteps;
-    const bool next_b = more && !(p.ablate & 1);
+    const bool next_b = more && !(p.ablate & (1 | 8));  // bit 3 (timing only, wrong results): no weight staging and
+                                                       // no barriers inside a chunk = bound of a register-fed B path
     const bool next_a = more && (cn != c || gn != g) && !(p.ablate & 1);  // this step ends (g, c): restage A after it
     long goff_next = goff_cur;
     if (gn != g && more) goff_next = p.seg_goff[gn];
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     // 2. MFMAs of (chunk c, tap t)
     if (!(p.ablate & 4)) {
       bf16x8 wf[NPL][4];
+      const unsigned char* Bb = Bb0 + (ks & 1) * b_img;
 #pragma unroll
       for (int q = 0; q < NPL; ++q)
 #pragma unroll
@@ -313,11 +320,14 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // every wave has read this step's fragments
+    if ((p.ablate & 8) && !next_a) { t = tn; c = cn; g = gn; goff_cur = goff_next; continue; }
+    // every wave has read this step's fragments — not needed for the weight tile alone when it goes to the other image
+    // (its last readers finished before the barrier that ended the previous step)
+    if (!p.bdouble || next_a) __syncthreads();
     // 3. commit the staged data
     if (next_b && !(p.ablate & 2)) {
 #pragma unroll
-      for (int q = 0; q < NPL; ++q) b_store(breg[q], q);
+      for (int q = 0; q < NPL; ++q) b_store(breg[q], q, (ks + 1) & 1);
     }
     if (next_a && !(p.ablate & 2)) {
 #pragma unroll
@@ -435,6 +445,11 @@ __global__ __launch_bounds__(256) void conv_wprep_kernel(const float* __restrict
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+inline bool no_bdouble() {
+  static const bool off = [] { const char* e = getenv("BLADES_IGEMM_BDOUBLE"); return e && atoi(e) == 0; }();
+  return off;
+}
+
 // Tile choice + geometry for one launch.  Returns the number of pixel fragments per wave (4, 2, 1), 0 = no fit.
 int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
   int aymin = 0, aymax = 0, axmin = 0, axmax = 0;
@@ -484,7 +499,9 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
       const int rows = q.TI > 1 ? (q.TI - 1) * (q.IR - share) + q.IR : q.IR;
       q.IS = q.TI > 1 ? (q.IR - share) * p.WS : q.IR * p.WS;
       q.NS = round_up(rows * p.WS + hpad + p.PL + 1, 4);
-      const long lds = (long)npl * q.NS * 64 + (long)npl * BN * 64;
+      long lds = (long)npl * q.NS * 64 + 2L * npl * BN * 64;
+      q.bdouble = 1;
+      if (lds > LDS_TOTAL / wgs_per_cu(mf) || no_bdouble()) { lds -= (long)npl * BN * 64; q.bdouble = 0; }
       q.region_px = q.TI * q.IR * p.Wi;
       const bool fits = lds <= LDS_TOTAL / wgs_per_cu(mf) && q.region_px < (1 << 20) && p.Wi < 4096 && q.IR * p.Wi < 4096 * 64;
       if (fits) {
@@ -512,7 +529,7 @@ int stats_chunks(const IgemmParams& p, int B) {
 
 template <int NPL, int MF, bool SPLIT>
 int launch(const IgemmParams& p, hipStream_t st) {
-  const size_t lds = (size_t)NPL * p.NS * 64 + (size_t)NPL * BN * 64;
+  const size_t lds = (size_t)NPL * p.NS * 64 + (size_t)(p.bdouble ? 2 : 1) * NPL * BN * 64;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<NPL, MF, SPLIT>),
