@@ -585,6 +585,9 @@ def _wgrad_plan(B, H, W, Ho, Wo, ks, stride, pad, device):
     # slots per line: padded width (+3 so the last quad of a ragged row stays inside the line),
     # made = 4 (mod 8) so lines sit 128 B (mod 256 B) apart -> adjacent-row quads do not bank-conflict
     need = W + 2 * pad + (3 if (W % 4 or _os.environ.get("BLADES_WGRAD_LINEPAD") == "3") else 0)
+    if stride == 1 and ks == 3:
+        # the stride-1 kernels read a row's tap columns as two quads per output quad: slots ow0 .. ow0 + 7
+        need = max(need, 4 * ((Wo + 3) // 4) + 4)
     if stride == 2:
         need = 2 * (-(-(W + 2 * pad) // 2) + 2)
     wslots = need

@@ -312,6 +312,9 @@ def test_fused_engine_gpu_matches_fp32_reference(dev, tmp_path, amp):
     (1, 5, 16, 48, 11, 3, 1, 1),
     (3, 4, 3, 64, 32, 3, 1, 1),
     (2, 4, 1, 32, 28, 3, 1, 1),
+    # unpadded 3x3 with power-of-two outputs (eight-wave kernel, window reads up to slot ow0 + 7 of a line)
+    (2, 4, 64, 64, 10, 3, 1, 0),
+    (3, 2, 64, 128, 18, 3, 1, 0),
     # headline-sized reductions: batch 64, odd client counts, block counts that are not multiples of 8
     (37, 64, 64, 64, 32, 3, 1, 1),
     (5, 64, 256, 512, 8, 1, 2, 0),
