@@ -45,6 +45,9 @@ class GradSink:
         # per-client weights (several local steps per round): [Kc, >= D] matrix whose row c holds client c's flat
         # parameters; None = every client shares the model's own parameters (FedSGD)
         self.W: Optional[torch.Tensor] = None
+        # True between FusedFedSGD.begin_round() / end_round(): the shared weights are constant, so every PCConv2d
+        # holds ready-made operand planes (ops.conv_planes) and no chunk splits the weights again
+        self.planes_valid = False
 
     def begin(self, block, scale, Kc, B):
         self.block, self.scale, self.Kc, self.B = block, scale, Kc, B
@@ -119,9 +122,41 @@ def dgrad_same_conv(gy: torch.Tensor, w: torch.Tensor, padding) -> torch.Tensor:
     return F.conv2d(gy, wt, None, 1, padding, 1, 1)
 
 
+class GradJoin:
+    """Meeting point of the two gradient branches of a residual block's input (main-branch first convolution and
+    shortcut).  Whichever backward node runs first leaves its tensor here and contributes no gradient of its own;
+    the second adds its result onto that tensor — a convolution does so in its data-gradient kernel's epilogue
+    (``conv_dgrad(accumulate_into=...)``) — and returns the sum.  No elementwise add pass over the activation-sized
+    tensor remains (2.6 % of the ResNet-18 round's kernel time, profiles/r2_v12_fp32_serial_kernel_stats_*)."""
+
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = None
+
+
+class _JoinTap(torch.autograd.Function):
+    """Identity on the shortcut branch; its backward hands the branch's gradient to the block's GradJoin."""
+
+    @staticmethod
+    def forward(ctx, x, join):
+        ctx.join = join
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        join = ctx.join
+        if join.pending is None:
+            join.pending = g
+            return None, None
+        total, join.pending = join.pending, None
+        return total.add_(g), None
+
+
 class _PCConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mod, want_stats=False):
+        ctx.join, mod.join = mod.join, None
         w = weight.to(x.dtype)
         b = mod.bias.to(x.dtype) if mod.bias is not None else None
         mod.bn_stats = None
@@ -145,28 +180,34 @@ class _PCConvFn(torch.autograd.Function):
             # the im2col tensor the forward pass is one K-step instead of nine and the weight gradient a plain
             # [pixels x 64]^T [pixels x 32] GEMM (a quarter of the MFMAs), for one extra 128-byte-per-pixel tensor.
             col = _stem_im2col(x, 3, 1)
-            wk = mod.sink.param(weight).detach()
-            w2 = F.pad(wk.reshape(*wk.shape[:-3], Ci * 9), (0, 32 - Ci * 9)).reshape(*wk.shape[:-3], 32, 1, 1)
+            planes = mod.planes("stem")
+            if planes is not None:
+                w2 = mod._planes["stem_w"]
+            else:
+                wk = mod.sink.param(weight).detach()
+                w2 = F.pad(wk.reshape(*wk.shape[:-3], Ci * 9), (0, 32 - Ci * 9)).reshape(*wk.shape[:-3], 32, 1, 1)
             ctx.stem = True
             ctx.save_for_backward(col, w2)
             if want_stats and _BN_STATS_IN_CONV:
                 y, mod.bn_stats = _hipmod().conv_forward(col, w2, mod.sink.param(mod.bias), 1, 0, mod.sink.npl,
-                                                         stats_B=x.shape[0] // mod.sink.Kc)
+                                                         stats_B=x.shape[0] // mod.sink.Kc, planes=planes)
                 return y
-            return _hipmod().conv_forward(col, w2, mod.sink.param(mod.bias), 1, 0, mod.sink.npl)
+            return _hipmod().conv_forward(col, w2, mod.sink.param(mod.bias), 1, 0, mod.sink.npl, planes=planes)
         if ctx.own:
             # hand-written implicit-GEMM kernel; reads the fp32 master weights itself (split into bf16 planes) —
             # the shared ones, or each client's own set when the sink carries per-client weights
             wk = mod.sink.param(weight).detach()
             ctx.save_for_backward(x, wk)
             Kc = mod.sink.Kc
+            planes = mod.planes("fwd")
             if want_stats and mod.sink.npl > 1 and Kc and x.shape[0] % Kc == 0 and _BN_STATS_IN_CONV:
                 # the BatchNorm that follows gets its per-client sums from this kernel's epilogue
                 y, mod.bn_stats = _hipmod().conv_forward(x, wk, mod.sink.param(mod.bias), int(mod.stride[0]),
-                                                         int(mod.padding[0]), mod.sink.npl, stats_B=x.shape[0] // Kc)
+                                                         int(mod.padding[0]), mod.sink.npl, stats_B=x.shape[0] // Kc,
+                                                         planes=planes)
                 return y
             return _hipmod().conv_forward(x, wk, mod.sink.param(mod.bias), int(mod.stride[0]), int(mod.padding[0]),
-                                          mod.sink.npl)
+                                          mod.sink.npl, planes=planes)
         if mod.sink.W is not None:
             raise NotImplementedError("per-client weights need the hand-written convolution kernels")
         ctx.save_for_backward(x, w)
@@ -192,9 +233,19 @@ class _PCConvFn(torch.autograd.Function):
                 g = gy.permute(0, 2, 3, 1)
                 sink.write(mod.bias, g.reshape(Kc, -1, gy.shape[1]).sum(dim=1, dtype=torch.float32))
             return None, None, None, None
+        join = ctx.join
         if ctx.needs_input_grad[0] and ctx.own:
+            other = None
+            if join is not None and join.pending is not None:
+                other, join.pending = join.pending, None
+                if not (other.dtype == x.dtype and other.shape == x.shape
+                        and other.is_contiguous(memory_format=torch.channels_last)):
+                    other = other.to(x.dtype).contiguous(memory_format=torch.channels_last)
             dx = _hipmod().conv_dgrad(gy, w, (int(x.shape[2]), int(x.shape[3])), int(mod.stride[0]),
-                                      int(mod.padding[0]), sink.npl)
+                                      int(mod.padding[0]), sink.npl, planes=mod.planes("dgrad"),
+                                      accumulate_into=other)
+            if join is not None and other is None:
+                join.pending, dx = dx, None  # first of the two branches: the other one adds onto this tensor
         elif ctx.needs_input_grad[0]:
             ks = w.shape[2:]
             same = (gy.is_cuda and _DGRAD_AS_FWD and tuple(mod.stride) == (1, 1) and tuple(mod.dilation) == (1, 1)
@@ -209,6 +260,12 @@ class _PCConvFn(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(
                     gy, x, w, None, mod.stride, mod.padding, mod.dilation, False, [0, 0], 1,
                     [True, False, False])[0]
+            if join is not None:
+                if join.pending is None:
+                    join.pending, dx = dx, None
+                else:
+                    other, join.pending = join.pending, None
+                    dx = other.add_(dx)
         if not mod.wgrad_hip(x, gy, Kc):
             sink.write(mod.weight, mod.wgrad(x, gy, Kc, B))  # [Kc, Cout, Cin, kh, kw]
         if mod.bias is not None:
@@ -226,9 +283,39 @@ class PCConv2d(nn.Module):
         self.stride, self.padding, self.dilation = list(conv.stride), list(conv.padding), list(conv.dilation)
         self.sink = sink
         self.bn_stats = None  # (partial, nchunk) of the last forward(..., want_stats=True), consumed by the BN
+        self.join = None      # GradJoin of the residual block whose input this convolution reads (set per forward)
+        self._planes = {}     # "fwd" / "dgrad" / "stem": ops.conv_planes images of the shared weight, per round
 
-    def forward(self, x, want_stats: bool = False):
+    def forward(self, x, want_stats: bool = False, join=None):
+        self.join = join
         return _PCConvFn.apply(x, self.weight, self, want_stats)
+
+    def prepare_planes(self):
+        """Splits the shared weight into the convolution kernels' bf16 operand planes — once per round, for every
+        chunk's forward and data-gradient launches (reference analogue: the weights a Ray worker receives once per
+        round, fllib/core/execution/worker_group.py:74-83)."""
+        w = self.weight.detach()
+        if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and _CONV_IMPL == "hip"):
+            return
+        h, npl, pl = _hipmod(), self.sink.npl, self._planes
+        w = w.contiguous()
+        Co, Ci, kh, kw = (int(v) for v in w.shape)
+        if kh * kw > 25:
+            return
+        pl["fwd"] = h.conv_planes(w, 0, npl, out=pl.get("fwd"))
+        pl["dgrad"] = h.conv_planes(w, 1, npl, out=pl.get("dgrad"))
+        if (_STEM_IM2COL and npl > 1 and Ci <= 3 and kh == kw == 3 and list(self.stride) == [1, 1]
+                and list(self.padding) == [1, 1]):
+            w2 = pl.get("stem_w")
+            if w2 is None:
+                w2 = pl["stem_w"] = torch.zeros((Co, 32, 1, 1), device=w.device, dtype=torch.float32)
+            w2.view(Co, 32)[:, : Ci * 9].copy_(w.reshape(Co, Ci * 9))
+            pl["stem"] = h.conv_planes(w2, 0, npl, out=pl.get("stem"))
+
+    def planes(self, kind: str):
+        if not self.sink.planes_valid or self.sink.W is not None:
+            return None
+        return self._planes.get(kind)
 
     def wgrad_hip(self, x, gy, Kc) -> bool:
         """MFMA kernel path: dW_c lands, scaled, in the update-matrix rows.  False = not applicable."""
@@ -623,11 +710,11 @@ class PCBatchNorm2d(nn.Module):
         return _PCBatchNormFn.apply(x, residual, anchor, self, relu, pre_stats)
 
 
-def _conv_bn(conv, bn, x, residual=None, relu: bool = False):
+def _conv_bn(conv, bn, x, residual=None, relu: bool = False, join=None):
     """``bn(conv(x))`` with the BatchNorm statistics taken from the convolution kernel's epilogue when both are
     the engine's own modules (no separate statistics pass over the convolution output)."""
     if isinstance(conv, PCConv2d) and isinstance(bn, PCBatchNorm2d):
-        y = conv(x, want_stats=True)
+        y = conv(x, want_stats=True, join=join)
         pre, conv.bn_stats = conv.bn_stats, None
         return bn(y, residual=residual, relu=relu, pre_stats=pre)
     return bn(conv(x), residual=residual, relu=relu)
@@ -643,10 +730,21 @@ class PCResBlock(nn.Module):
 
     def forward(self, x):
         b = self.blk
-        sc = x
+        # The block input's gradient has two branches (first convolution, shortcut): the second data-gradient
+        # kernel to run adds onto the first one's tensor (GradJoin) instead of autograd adding the two afterwards.
+        join = None
+        if (torch.is_grad_enabled() and x.requires_grad and x.is_cuda and isinstance(b.conv1, PCConv2d)
+                and _own_conv(x, b.conv1) and _os.environ.get("BLADES_GRAD_JOIN", "1") != "0"):
+            join = GradJoin()
         if len(b.shortcut) > 0:
-            sc = _conv_bn(b.shortcut[0], b.shortcut[1], x)
-        out = _conv_bn(b.conv1, b.bn1, x, relu=True)
+            sc = _conv_bn(b.shortcut[0], b.shortcut[1], x, join=join if isinstance(b.shortcut[0], PCConv2d) else None)
+            if join is not None and not isinstance(b.shortcut[0], PCConv2d):
+                join = None
+        out = _conv_bn(b.conv1, b.bn1, x, relu=True, join=join)
+        if len(b.shortcut) == 0:
+            # (after conv1: the tap's backward node is then the younger one and runs first, so the convolution's
+            # data-gradient kernel is the branch that does the adding)
+            sc = _JoinTap.apply(x, join) if join is not None else x
         if self.bottleneck:
             out = _conv_bn(b.conv2, b.bn2, out, relu=True)
             return _conv_bn(b.conv3, b.bn3, out, residual=sc, relu=True)
@@ -766,6 +864,19 @@ class FusedFedSGD:
         self.amp_dtype = amp_dtype
         self.device = device
         self.sink.npl = 1 if amp_dtype == torch.bfloat16 else (2 if conv_planes == 2 else 3)
+
+    def begin_round(self):
+        """The shared weights stay as they are until ``end_round()``: split every convolution's weight into its
+        operand planes now, once, on the current stream (before the chunk streams fork from it)."""
+        if self.device.type != "cuda" or _os.environ.get("BLADES_ROUND_PLANES", "1") == "0":
+            return
+        for m in self.template.modules():
+            if isinstance(m, PCConv2d):
+                m.prepare_planes()
+        self.sink.planes_valid = True
+
+    def end_round(self):
+        self.sink.planes_valid = False
 
     def run(self, X: torch.Tensor, Y: torch.Tensor, block: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
         """X [Kc, B, ...], Y [Kc, B]; ``block`` = the chunk's rows of U (row stride

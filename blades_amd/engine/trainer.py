@@ -674,6 +674,10 @@ class ClientEngine:
         # with any of those the exchange cannot start early
         late = bool(seq) or self._has_round_end_hooks()
         self._exchange_begin()
+        if self.fused is not None and self.nb == 1:
+            # theta does not change until the server step: the convolution weights are split into their operand
+            # planes once, here, instead of once per chunk and launch
+            self.fused.begin_round()
         # Optional: chunks alternate between `n_streams` HIP streams so that one chunk's memory-bound kernels
         # (per-client BN, elementwise) can overlap another chunk's MFMA-bound convolutions.
         n_streams = self.n_streams if (dev.type == "cuda" and not late) else 1
@@ -717,6 +721,8 @@ class ClientEngine:
                     self._exchange_upto(int(self._train_rows[batched[c0]]))
         for st in streams or []:
             torch.cuda.current_stream().wait_stream(st)
+        if self.fused is not None:
+            self.fused.end_round()
         for ls, cnt in pending:
             loss_sum += ls
             loss_cnt += cnt
@@ -937,6 +943,8 @@ class ClientEngine:
         by_len: Dict[int, List[int]] = {}
         for r, n in enumerate(st.lengths):
             by_len.setdefault(int(n), []).append(r)
+        if self.fused is not None:
+            self.fused.begin_round()  # one weight-plane split for all evaluation batches
         for n, rs in by_len.items():
             if n == 0:
                 continue
@@ -953,6 +961,8 @@ class ClientEngine:
                     logits = vf(X)
                     acc += ops.ce_topk(logits.reshape(-1, logits.shape[-1]), Y.reshape(-1), ks)  # fused CE + top-k
                     count += Y.numel()
+        if self.fused is not None:
+            self.fused.end_round()
         acc = torch.cat([acc, torch.tensor([float(count)], device=self.device, dtype=torch.float64)])
         self.ctx.all_reduce(acc)
         vals = acc.tolist()

@@ -928,9 +928,41 @@ def conv_igemm_supported(x: torch.Tensor, weight: torch.Tensor, stride, pad, dil
             and x.shape[3] + 2 * pad[1] >= kw and x.shape[3] <= 256)
 
 
-def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, mode, npl, stats_B=0):
+def _opt_sig(name, argtypes, restype=None):
+    """A symbol newer than the oldest library ``BLADES_HIP_LIB`` may point at (same-box A/B runs): None if absent."""
+    return _sig(name, argtypes, restype) if hasattr(_lib, name) else None
+
+
+_conv_igemm2 = _opt_sig("blades_conv_igemm2", [_P, _P, _P, _P, _P] + [c_int] * 14 + [c_long, c_long, _P, c_int, c_int, _P],
+                        c_int)
+_conv_wprep = _opt_sig("blades_conv_wprep", [_P, _P] + [c_int] * 7 + [c_long, _P], c_int)
+
+
+def conv_planes(weight, mode: int, npl: int, out=None):
+    """bf16 operand planes of a shared convolution weight ``[Co, Ci, kh, kw]`` for ``conv_forward`` (mode 0) /
+    ``conv_dgrad`` (mode 1): the split / transposed / padded image the kernel stages its weight tiles from.  Built
+    once per layer and round by the FedSGD engine (the weights do not change while the clients train) instead of
+    once per chunk and call.  ``out``: a buffer of a previous call for the same weight shape, reused in place."""
+    w = weight.detach()
+    if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and w.is_contiguous()):
+        raise ValueError("conv_planes: weight must be a contiguous CUDA fp32 [Co, Ci, kh, kw] tensor")
+    if _conv_wprep is None:
+        return None
+    Co, Ci, kh, kw = (int(v) for v in w.shape)
+    n = _conv_igemm_ws(Co, Ci, kh, kw, mode, npl, 1)
+    if out is None or out.numel() != n or out.device != w.device:
+        out = _empty(n, dtype=torch.uint8, device=w.device)
+    rc = _conv_wprep(_ptr(w), _ptr(out), Co, Ci, kh, kw, mode, npl, 1, 0, _stream())
+    if rc != 0:
+        raise ValueError(f"conv_planes: rejected (rc={rc})")
+    return out
+
+
+def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, mode, npl, stats_B=0, planes=None,
+               accumulate=False):
     """``weight``: [Co, Ci, kh, kw] shared by every image, or [Kc, Co, Ci, kh, kw] — one weight set per client
-    (clients may be rows of a wider matrix: any stride along dim 0, contiguous inside a client)."""
+    (clients may be rows of a wider matrix: any stride along dim 0, contiguous inside a client).  ``planes``: the
+    ``conv_planes`` image of a shared weight (the weight itself is then not read)."""
     w = weight.detach()
     nc, wstride, bstride = 1, 0, 0
     if w.dim() == 5:
@@ -949,16 +981,32 @@ def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, 
             bstride, bias = int(b.stride(0)), b
         else:
             bias = _vec(b, Co, inp.device, name="bias")
-    ws = _empty(_conv_igemm_ws(Co, Ci, kh, kw, mode, npl, nc), dtype=torch.uint8, device=inp.device)
+    need = _conv_igemm_ws(Co, Ci, kh, kw, mode, npl, nc)
+    flags = 0
+    if planes is not None and nc == 1 and _conv_igemm2 is not None:
+        if not (planes.is_cuda and planes.dtype == torch.uint8 and planes.is_contiguous() and planes.numel() == need):
+            raise ValueError("conv_igemm: `planes` is not the conv_planes image of this weight shape / mode")
+        ws, flags = planes, 1
+    else:
+        ws = _empty(need, dtype=torch.uint8, device=inp.device)
+    if accumulate:
+        if _conv_igemm2 is None:
+            raise RuntimeError("conv_igemm: this library build has no accumulate mode")
+        flags |= 2
     partial, nch = None, 0
     if stats_B and mode == 0 and npl > 1:
         # BatchNorm partial sums from the epilogue, when no tile of the planned launch straddles two clients
         nch = _conv_igemm_stats_nchunk(N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, npl, nc, int(stats_B))
         if nch > 0:
             partial = _empty((N // int(stats_B)) * nch * Co * 2, device=inp.device)
-    rc = _conv_igemm(_ptr(inp), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad,
-                     mode, npl, nc, wstride, bstride, _ptr(partial), int(stats_B) if partial is not None else 0,
-                     _stream())
+    if _conv_igemm2 is not None:
+        rc = _conv_igemm2(_ptr(inp), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, H, W, Ci, Ho, Wo, Co, kh, kw, stride,
+                          pad, mode, npl, nc, wstride, bstride, _ptr(partial),
+                          int(stats_B) if partial is not None else 0, flags, _stream())
+    else:
+        rc = _conv_igemm(_ptr(inp), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, H, W, Ci, Ho, Wo, Co, kh, kw, stride,
+                         pad, mode, npl, nc, wstride, bstride, _ptr(partial),
+                         int(stats_B) if partial is not None else 0, _stream())
     if rc != 0:
         raise ValueError(f"conv_igemm: unsupported configuration (rc={rc}): N={N} H={H} W={W} Ci={Ci} Co={Co} "
                          f"k={kh}x{kw} stride={stride} pad={pad} mode={mode} npl={npl}")
@@ -979,7 +1027,7 @@ def stem_im2col(x: torch.Tensor, k: int, pad: int) -> torch.Tensor:
     return out
 
 
-def conv_forward(x, weight, bias, stride: int, pad: int, npl: int, stats_B: int = 0):
+def conv_forward(x, weight, bias, stride: int, pad: int, npl: int, stats_B: int = 0, planes=None):
     """y = conv2d(x, weight, bias) for channels-last x; fp32 (npl 3 / 2) or bf16 (npl 1) in and out.
     ``stats_B`` > 0 (fp32 tensors, ``stats_B`` images per client): returns ``(y, pre_stats)`` where ``pre_stats`` is
     the ``(partial, nchunk)`` pair ``pcbn_forward`` accepts, or ``None`` if this geometry cannot provide it."""
@@ -995,12 +1043,14 @@ def conv_forward(x, weight, bias, stride: int, pad: int, npl: int, stats_B: int 
     y = _empty((N, Co, Ho, Wo), dtype=dt, device=x.device, memory_format=torch.channels_last)
     if Co == 1 or Ho * Wo == 1:
         y = y.as_strided(y.shape, (Ho * Wo * Co, 1, Wo * Co, Co))
-    pre = _conv_call(x, weight, bias, y, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 0, npl, stats_B)
+    pre = _conv_call(x, weight, bias, y, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 0, npl, stats_B, planes=planes)
     return (y, pre) if stats_B else y
 
 
-def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int):
-    """dx of conv2d(x, weight) given gy (channels-last); ``in_hw`` = (H, W) of x."""
+def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int, planes=None, accumulate_into=None):
+    """dx of conv2d(x, weight) given gy (channels-last); ``in_hw`` = (H, W) of x.  ``accumulate_into``: a tensor of
+    dx's shape and layout that the result is added to in the kernel's epilogue (and that is returned) — the other
+    gradient branch of a residual block, so no separate elementwise add runs over the tensor."""
     dt = torch.bfloat16 if npl == 1 else torch.float32
     _chk_nhwc(gy, "gy", dt)
     N, Co, Ho, Wo = gy.shape
@@ -1008,10 +1058,17 @@ def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int):
     H, W = in_hw
     if Co2 != Co or Ho != (H + 2 * pad - kh) // stride + 1 or Wo != (W + 2 * pad - kw) // stride + 1:
         raise ValueError("conv_dgrad: gy does not match the convolution geometry")
-    dx = _empty((N, Ci, H, W), dtype=dt, device=gy.device, memory_format=torch.channels_last)
-    if Ci == 1 or H * W == 1:
-        dx = dx.as_strided(dx.shape, (H * W * Ci, 1, W * Ci, Ci))
-    _conv_call(gy, weight, None, dx, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 1, npl)
+    if accumulate_into is not None:
+        dx = accumulate_into
+        _chk_nhwc(dx, "accumulate_into", dt)
+        if tuple(dx.shape) != (N, Ci, H, W):
+            raise ValueError(f"conv_dgrad: accumulate_into has shape {tuple(dx.shape)}, expected {(N, Ci, H, W)}")
+    else:
+        dx = _empty((N, Ci, H, W), dtype=dt, device=gy.device, memory_format=torch.channels_last)
+        if Ci == 1 or H * W == 1:
+            dx = dx.as_strided(dx.shape, (H * W * Ci, 1, W * Ci, Ci))
+    _conv_call(gy, weight, None, dx, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 1, npl, planes=planes,
+               accumulate=accumulate_into is not None)
     return dx
 
 

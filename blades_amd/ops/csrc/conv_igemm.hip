@@ -54,6 +54,7 @@ constexpr int BN = 64;        // output channels per workgroup
 constexpr int MAXTAPS = 25;
 constexpr int MAXSEG = 16;    // reduction segments (input parity classes of a strided forward convolution)
 constexpr int LDS_TOTAL = 160 * 1024;
+constexpr int RED_BYTES = 4 * 64 * 2 * 4;  // epilogue scratch of the BatchNorm partial sums: [4 waves][64 ch][2]
 // two workgroups per CU (<= 80 KB LDS, <= 256 registers each); three smaller ones measured slower (MF = 2: 5.7 vs
 // 5.2 ms on the 64-channel layer: the weight-fragment reads per MFMA double)
 constexpr int wgs_per_cu(int) { return 2; }
@@ -85,6 +86,8 @@ struct IgemmParams {
   int nseg;                   // reduction segments: segment g = taps [seg_begin[g], seg_begin[g + 1]) on the input view
   int seg_begin[MAXSEG + 1];  // that starts seg_goff[g] elements into the image (all views have the same size)
   long seg_goff[MAXSEG];
+  int accumulate;             // out += result (the data gradient of a residual block's first convolution lands on the
+                              // shortcut branch's gradient: no separate elementwise add over the tensor)
   int Hphys, Wphys, in_rm, in_cm;  // the input may be a strided view in[:, ::rm, ::cm] of a [Hphys][Wphys] image (a
                                    // strided 1x1 convolution only ever touches those pixels: it runs as a stride-1
                                    // convolution on the view, staging a quarter of the pixels)
@@ -109,24 +112,46 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   constexpr int MAXPF = max_prefetch(MF);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per_xcd = gridDim.x >> 3;
-  const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (lid >= p.n_mtiles * p.n_ntiles) return;  // whole workgroup leaves: no barrier is skipped by a subset
-  const int nt = lid % p.n_ntiles, mt = lid / p.n_ntiles;
-  const int n0 = nt * BN;
-  int img0, sy0;
-  if (p.TI == 1) { img0 = mt / p.tiles_per_img; sy0 = (mt - img0 * p.tiles_per_img) * p.TR; }
-  else { img0 = mt * p.TI; sy0 = 0; }
-  const int iy_lo = sy0 * p.si + p.aymin;
-  // per-client weights: a tile never straddles two clients (plan() keeps TI a divisor of imgs_per_client)
-  const int client = p.n_clients > 1 ? img0 / p.imgs_per_client : 0;
-  const unsigned short* wp_c = p.wp + (size_t)client * p.wp_client_stride;
-  const float* bias_c = p.bias ? p.bias + (size_t)client * p.bias_client_stride : nullptr;
+  // Persistent tiles.  The grid holds at most the workgroups that are resident at once (two per CU); a workgroup
+  // walks the tiles lid, lid + stride, ... of its XCD's contiguous tile range (neighbouring tiles share halo rows,
+  // all channel tiles of a pixel tile share the input through that XCD's L2).  A tile boundary is treated like a
+  // chunk boundary of the K loop: the next tile's first weight tile and first input chunk are fetched under the
+  // last step's MFMAs and committed behind it, the finished tile's stores drain under the next tile's MFMAs, so
+  // neither the prologue's load latency nor the epilogue's store burst is exposed once per tile (they were: all
+  // workgroups of a launch start together and stay in phase, the chip alternated between an HBM phase and an MFMA
+  // phase).
+  const int ntiles = p.n_mtiles * p.n_ntiles;
+  const int wg_per_xcd = gridDim.x >> 3;  // the grid is a multiple of 8
+  const int tiles_per_xcd = (ntiles + 7) >> 3;
+  const int tile_lo = (blockIdx.x & 7) * tiles_per_xcd;
+  const int tile_hi = tile_lo + tiles_per_xcd < ntiles ? tile_lo + tiles_per_xcd : ntiles;
+  int lid = tile_lo + (blockIdx.x >> 3);
+  if (lid >= tile_hi) return;  // whole workgroup leaves: no barrier is skipped by a subset
+
+  struct Tile {
+    int n0, img0, sy0, mt, client;
+    __device__ __forceinline__ int iy_lo(const IgemmParams& p) const { return sy0 * p.si + p.aymin; }
+    // per-client weights: a tile never straddles two clients (plan() keeps TI a divisor of imgs_per_client)
+    __device__ __forceinline__ const unsigned short* wp(const IgemmParams& p) const {
+      return p.wp + (size_t)client * p.wp_client_stride;
+    }
+  };
+  auto tile_ctx = [&](int id) {
+    Tile T;
+    const int nt = id % p.n_ntiles;
+    T.mt = id / p.n_ntiles;
+    T.n0 = nt * BN;
+    if (p.TI == 1) { T.img0 = T.mt / p.tiles_per_img; T.sy0 = (T.mt - T.img0 * p.tiles_per_img) * p.TR; }
+    else { T.img0 = T.mt * p.TI; T.sy0 = 0; }
+    T.client = p.n_clients > 1 ? T.img0 / p.imgs_per_client : 0;
+    return T;
+  };
 
   const int a_plane = p.NS * 64, a_buf = NPL * a_plane;
   constexpr int b_plane = BN * 64;
   unsigned char* A_lds = smem;          // [NPL][NS slots][32 ch] bf16
   unsigned char* B_lds = smem + a_buf;  // [NPL][64 co][32 ci] bf16
+  // zero fill, once: the slots no staging pass ever writes (horizontal padding between rows) stay zero for every tile
   for (int i = tid * 16; i < a_buf; i += 256 * 16) *reinterpret_cast<u32x4*>(A_lds + i) = u32x4{0, 0, 0, 0};
 
   // Both LDS images have 64-byte rows (32 channels of one slot / one output channel).  A fragment read
@@ -135,34 +160,25 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   // makes those reads conflict-free.  Stores apply the same involution.
   auto swz = [](int row) { return (row & 4) << 3; };
 
-  // ---- this lane's output pixels: fragment pf, column li ---------------------------------------------------
   const int li = lane & 15, kg = lane >> 4;
-  int a_slot[MF];
-  long out_pix[MF];
-#pragma unroll
-  for (int pf = 0; pf < MF; ++pf) {
-    const int m = (wave * MF + pf) * 16 + li;
-    const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
-    const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
-    const bool ok = il < p.TI && sy0 + ry < p.Hs && img0 + il < p.N;
-    a_slot[pf] = ok ? il * p.IS + ry * p.si * p.WS + sx * p.si + p.PL : p.PL;
-    out_pix[pf] = ok ? ((long)(img0 + il) * p.Hout + (sy0 + ry) * p.so + p.poy) * p.Wout + sx * p.so + p.pox : -1;
-  }
 
   // ---- staging roles -----------------------------------------------------------------------------------------
   // A: one pass = PIXPP region pixels x 32 channels; lane group (cg) covers CPL channels of a pixel (16 bytes)
   constexpr int CPL = SPLIT ? 4 : 8, LPP = KC / CPL, PIXPP = 256 / LPP;
   const int cg = tid % LPP, pp = tid / LPP;
-  struct ADesc { long goff; int slot; };
-  auto a_desc = [&](int pass, long seg_goff) {
+  struct ADesc { long goff; int slot; };  // goff < 0: nothing to load (the slot gets zeros); slot < 0: not a slot
+  // (`ppx`: the thread's pixel index within a pass, handed in through an opaque copy at every staging site — the
+  // descriptors of all passes are invariant per lane and the compiler otherwise keeps them, three dozen registers,
+  // alive through the whole K loop)
+  auto a_desc = [&](int pass, long seg_goff, const Tile& T, int ppx) {
     ADesc d;
-    const int e = pass * PIXPP + pp;
+    const int e = pass * PIXPP + ppx;
     const int il = fdiv(e, p.inv_irwi), rem = e - il * p.IR * p.Wi;
     const int r = fdiv(rem, p.inv_wi), ix = rem - r * p.Wi;
-    const int iy = iy_lo + r;
-    const bool ok = e < p.region_px && (unsigned)iy < (unsigned)p.Hi && img0 + il < p.N;
-    d.slot = il * p.IS + r * p.WS + ix + p.PL;
-    d.goff = ok ? (((long)(img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci + seg_goff
+    const int iy = T.iy_lo(p) + r;
+    const bool ok = e < p.region_px && (unsigned)iy < (unsigned)p.Hi && T.img0 + il < p.N;
+    d.slot = e < p.region_px ? il * p.IS + r * p.WS + ix + p.PL : -1;
+    d.goff = ok ? (((long)(T.img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci + seg_goff
                 : -1;
     return d;
   };
@@ -192,8 +208,9 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     }
     return v;
   };
+  // every slot of the region is written, rows outside the image with zeros: the previous tile's rows may sit there
   auto a_store = [&](const ADesc& d, u32x4 v) {
-    if (d.goff < 0) return;  // outside the image / region: the slot keeps its zero fill
+    if (d.slot < 0) return;
     if constexpr (SPLIT) {
       unsigned char* dst = A_lds + d.slot * 64 + (((cg >> 1) * 16) ^ swz(d.slot)) + (cg & 1) * 8;
       u32x2 pl[NPL];
@@ -205,14 +222,16 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     }
   };
   // whole-chunk staging with every load of a batch in flight before the first conversion
-  auto a_stage_sync = [&](int pass_begin, int c0, long seg) {
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto a_stage_sync = [&](int pass_begin, int c0, long seg, const Tile& T) {
+    const int ppx = opaque(pp);
     for (int j0 = pass_begin; j0 < p.npass; j0 += 4) {
       ADesc d[4];
       u32x4 v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        d[j].goff = -1; d[j].slot = 0;
-        if (j0 + j < p.npass) d[j] = a_desc(j0 + j, seg);
+        d[j].goff = -1; d[j].slot = -1;
+        if (j0 + j < p.npass) d[j] = a_desc(j0 + j, seg, T, ppx);
         v[j] = a_load(d[j], c0);
       }
 #pragma unroll
@@ -222,198 +241,241 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   // B: weight tile of one step = NPL x [64 co][32 ci]; thread -> (co row tid >> 2, 8-channel group tid & 3)
   const int brow = tid >> 2, bkg = tid & 3;
   const size_t w_plane = (size_t)p.ntw * p.Cop * p.Cip;
-  auto b_load = [&](int tw, int c0, int q) {
-    return *reinterpret_cast<const u32x4*>(wp_c + q * w_plane + ((size_t)tw * p.Cop + n0 + brow) * p.Cip + c0 + bkg * 8);
+  auto b_load = [&](int tw, int c0, int q, const Tile& T) {
+    return *reinterpret_cast<const u32x4*>(T.wp(p) + q * w_plane + ((size_t)tw * p.Cop + T.n0 + brow) * p.Cip + c0 + bkg * 8);
   };
   const int b_dst = brow * 64 + ((bkg * 16) ^ swz(brow));
   const int b_img = p.bdouble ? NPL * b_plane : 0;  // distance between the two weight-tile images
   auto b_store = [&](u32x4 v, int q, int img) {
     *reinterpret_cast<u32x4*>(B_lds + img * b_img + q * b_plane + b_dst) = v;
   };
-
-  f32x4 acc[MF][4];
-#pragma unroll
-  for (int pf = 0; pf < MF; ++pf)
-#pragma unroll
-    for (int cf = 0; cf < 4; ++cf) acc[pf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float* red = reinterpret_cast<float*>(smem + a_buf + (p.bdouble ? 2 : 1) * NPL * b_plane);  // [4 waves][64 ch][2]
 
   const int nchunks = p.Cip / KC, nsteps = nchunks * p.ntaps;
+  Tile cur = tile_ctx(lid);
   __syncthreads();  // zero fill complete
-  if (nsteps > 0) {
-    a_stage_sync(0, 0, p.seg_goff[0]);
+  if (nsteps > 0) {  // (no taps: an output parity class of a strided data gradient that no filter tap reaches = zeros)
+    a_stage_sync(0, 0, p.seg_goff[0], cur);
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q, 0);
+    for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q, cur), q, 0);
   }
   __syncthreads();
 
   const unsigned char* Bb0 = B_lds + li * 64 + ((kg * 16) ^ swz(li));
-  // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
-  // (segment, chunk) pair changes
-  int g = 0, c = 0, t = 0;
-  long goff_cur = p.seg_goff[0];
   // The tap tables live in one register each (lane i holds entry i) and are read with v_readlane: a kernel-argument
   // load indexed by the step's tap has the latency of a cache access, shares its counter with the LDS reads, and sat
   // in front of every step's weight prefetch and fragment-read burst.
   static_assert(MAXTAPS <= 64, "one lane per tap");
   const int lane_toff = p.tap_off[lane < MAXTAPS ? lane : 0], lane_tw = p.tap_w[lane < MAXTAPS ? lane : 0];
-  int seg_lo = p.seg_begin[0], seg_hi = p.seg_begin[1];  // taps of segment g (kept in registers: a kernel-argument
-                                                         // load per step shows in the short steps of the bf16 kernels)
-  for (int ks = 0; ks < nsteps; ++ks) {
-    int tn = t + 1, cn = c, gn = g;
-    if (tn == seg_hi) {
-      tn = seg_lo; cn = c + 1;
-      if (cn == nchunks) { cn = 0; gn = g + 1; tn = seg_hi; }
-    }
-    const bool more = ks + 1 < nsteps;
-    const bool next_b = more && !(p.ablate & (1 | 8));  // bit 3 (timing only, wrong results): no weight staging and
-                                                       // no barriers inside a chunk = bound of a register-fed B path
-    const bool next_a = more && (cn != c || gn != g) && !(p.ablate & 1);  // this step ends (g, c): restage A after it
-    long goff_next = goff_cur;
-    if (gn != g && more) goff_next = p.seg_goff[gn];
-    const int toff = __builtin_amdgcn_readlane(lane_toff, t);
-    // 1. global loads: next step's weight tile; at a chunk's last tap also the next chunk of the input tile.
-    //    They complete under this step's MFMAs (and under the MFMAs of the workgroup sharing the CU).
-    u32x4 breg[NPL];
-    if (next_b) {
-      const int tw = __builtin_amdgcn_readlane(lane_tw, tn);
-#pragma unroll
-      for (int q = 0; q < NPL; ++q) breg[q] = b_load(tw, cn * KC, q);
-    }
-    u32x4 areg[MAXPF];
-    if (next_a) {
-#pragma unroll
-      for (int j = 0; j < MAXPF; ++j) {
-        areg[j] = u32x4{0, 0, 0, 0};
-        if (j < p.npass) areg[j] = a_load(a_desc(j, goff_next), cn * KC);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // 2. MFMAs of (chunk c, tap t)
-    if (!(p.ablate & 4)) {
-      bf16x8 wf[NPL][4];
-      const unsigned char* Bb = Bb0 + (ks & 1) * b_img;
-#pragma unroll
-      for (int q = 0; q < NPL; ++q)
-#pragma unroll
-        for (int cf = 0; cf < 4; ++cf) wf[q][cf] = *reinterpret_cast<const bf16x8*>(Bb + q * b_plane + cf * 1024);
-#pragma unroll
-      for (int pf = 0; pf < MF; ++pf) {
-        const int s = a_slot[pf] + toff;
-        const unsigned char* Ab = A_lds + s * 64 + ((kg * 16) ^ swz(s));
-        bf16x8 af[NPL];
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) af[q] = *reinterpret_cast<const bf16x8*>(Ab + q * a_plane);
-#pragma unroll
-        for (int cf = 0; cf < 4; ++cf) {
-          // (weight plane, activation plane) pairs, small terms first
-          if constexpr (NPL == 3) {
-            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[1], acc[pf][cf], 0, 0, 0);
-            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[2], acc[pf][cf], 0, 0, 0);
-            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][cf], af[0], acc[pf][cf], 0, 0, 0);
-          }
-          if constexpr (NPL >= 2) {
-            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[1], acc[pf][cf], 0, 0, 0);
-            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[0], acc[pf][cf], 0, 0, 0);
-          }
-          acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[0], acc[pf][cf], 0, 0, 0);
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if ((p.ablate & 8) && !next_a) { t = tn; c = cn; g = gn; goff_cur = goff_next; continue; }
-    // every wave has read this step's fragments — not needed for the weight tile alone when it goes to the other image
-    // (its last readers finished before the barrier that ended the previous step)
-    if (!p.bdouble || next_a) __syncthreads();
-    // 3. commit the staged data
-    if (next_b && !(p.ablate & 2)) {
-#pragma unroll
-      for (int q = 0; q < NPL; ++q) b_store(breg[q], q, (ks + 1) & 1);
-    }
-    if (next_a && !(p.ablate & 2)) {
-#pragma unroll
-      for (int j = 0; j < MAXPF; ++j)
-        if (j < p.npass) a_store(a_desc(j, goff_next), areg[j]);
-      a_stage_sync(MAXPF, cn * KC, goff_next);  // geometries with more than MAXPF passes: the rest without prefetch
-    }
-    __syncthreads();
-    if (gn != g && more) { seg_lo = seg_hi; seg_hi = p.seg_begin[gn + 1]; }
-    t = tn; c = cn; g = gn; goff_cur = goff_next;
-  }
-
-  // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
   const bool vec_out = (p.Co % 4) == 0;
   const bool want_stats = SPLIT && p.stats != nullptr;  // block-uniform
-  f32x4 st_s[4], st_q[4];
+  unsigned gstep = 0;  // steps since the kernel began: the weight tile of step s sits in image s & 1
+
+  for (;;) {
+    const int lid_next = lid + wg_per_xcd;
+    const bool has_next = lid_next < tile_hi;
+    const Tile nxt = tile_ctx(has_next ? lid_next : lid);
+    // ---- this lane's input slots: fragment pf, column li (the output addresses are derived again in the epilogue:
+    // they would occupy registers through the whole K loop) ----------------------------------------------------
+    int a_slot[MF];
 #pragma unroll
-  for (int cf = 0; cf < 4; ++cf) { st_s[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; st_q[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int pf = 0; pf < MF; ++pf) {
+      const int m = (wave * MF + pf) * 16 + li;
+      const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
+      const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
+      const bool ok = il < p.TI && cur.sy0 + ry < p.Hs && cur.img0 + il < p.N;
+      a_slot[pf] = ok ? il * p.IS + ry * p.si * p.WS + sx * p.si + p.PL : p.PL;
+    }
+    f32x4 acc[MF][4];
 #pragma unroll
-  for (int pf = 0; pf < MF; ++pf) {
-    if (out_pix[pf] < 0) continue;
+    for (int pf = 0; pf < MF; ++pf)
 #pragma unroll
-    for (int cf = 0; cf < 4; ++cf) {
-      const int co = n0 + cf * 16 + kg * 4;
-      if (co >= p.Co) continue;
-      f32x4 v = acc[pf][cf];
-      if (bias_c != nullptr) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? bias_c[co + j] : 0.f;
+      for (int cf = 0; cf < 4; ++cf) acc[pf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
+    // (segment, chunk) pair changes
+    int g = 0, c = 0, t = 0;
+    long goff_cur = p.seg_goff[0];
+    int seg_lo = p.seg_begin[0], seg_hi = p.seg_begin[1];  // taps of segment g (kept in registers: a kernel-argument
+                                                           // load per step shows in the short steps of the bf16 kernels)
+    for (int ks = 0; ks < nsteps; ++ks, ++gstep) {
+      int tn = t + 1, cn = c, gn = g;
+      if (tn == seg_hi) {
+        tn = seg_lo; cn = c + 1;
+        if (cn == nchunks) { cn = 0; gn = g + 1; tn = seg_hi; }
       }
-      if (want_stats) { st_s[cf] += v; st_q[cf] += v * v; }
-      if constexpr (SPLIT) {
-        float* dst = reinterpret_cast<float*>(p.out) + out_pix[pf] * p.Co + co;
-        if (vec_out) *reinterpret_cast<f32x4*>(dst) = v;
-        else {
+      const bool last = ks + 1 == nsteps;  // the step after this one opens the next tile
+      if (last) { tn = 0; cn = 0; gn = 0; }
+      const bool more = !last || has_next;
+      Tile T = cur;  // (by value: a reference to one of two objects would put both in memory)
+      if (last) T = nxt;
+      const bool next_b = more && !(p.ablate & (1 | 8));  // bit 3 (timing only, wrong results): no weight staging and
+                                                         // no barriers inside a chunk = bound of a register-fed B path
+      const bool next_a = more && (last || cn != c || gn != g) && !(p.ablate & 1);  // restage A after this step
+      long goff_next = goff_cur;
+      if ((gn != g || last) && more) goff_next = p.seg_goff[gn];
+      const int toff = __builtin_amdgcn_readlane(lane_toff, t);
+      // 1. global loads: next step's weight tile; at a chunk's (tile's) last tap also the next chunk of the input
+      //    tile.  They complete under this step's MFMAs (and under the MFMAs of the workgroup sharing the CU).
+      u32x4 breg[NPL];
+      if (next_b) {
+        const int tw = __builtin_amdgcn_readlane(lane_tw, tn);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = v[j];
+        for (int q = 0; q < NPL; ++q) breg[q] = b_load(tw, cn * KC, q, T);
+      }
+      u32x4 areg[MAXPF];
+      if (next_a) {
+        const int ppx = opaque(pp);
+#pragma unroll
+        for (int j = 0; j < MAXPF; ++j) {
+          areg[j] = u32x4{0, 0, 0, 0};
+          if (j < p.npass) areg[j] = a_load(a_desc(j, goff_next, T, ppx), cn * KC);
         }
-      } else {
-        unsigned short* dst = reinterpret_cast<unsigned short*>(p.out) + out_pix[pf] * p.Co + co;
-        const u32x2 b = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
-        if (vec_out) *reinterpret_cast<u32x2*>(dst) = b;
-        else {
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // 2. MFMAs of (chunk c, tap t)
+      if (!(p.ablate & 4)) {
+        bf16x8 wf[NPL][4];
+        const unsigned char* Bb = Bb0 + (gstep & 1) * b_img;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = (unsigned short)(b[j >> 1] >> ((j & 1) * 16));
+        for (int q = 0; q < NPL; ++q)
+#pragma unroll
+          for (int cf = 0; cf < 4; ++cf) wf[q][cf] = *reinterpret_cast<const bf16x8*>(Bb + q * b_plane + cf * 1024);
+#pragma unroll
+        for (int pf = 0; pf < MF; ++pf) {
+          const int s = a_slot[pf] + toff;
+          const unsigned char* Ab = A_lds + s * 64 + ((kg * 16) ^ swz(s));
+          bf16x8 af[NPL];
+#pragma unroll
+          for (int q = 0; q < NPL; ++q) af[q] = *reinterpret_cast<const bf16x8*>(Ab + q * a_plane);
+#pragma unroll
+          for (int cf = 0; cf < 4; ++cf) {
+            // (weight plane, activation plane) pairs, small terms first
+            if constexpr (NPL == 3) {
+              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[1], acc[pf][cf], 0, 0, 0);
+              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[2], acc[pf][cf], 0, 0, 0);
+              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][cf], af[0], acc[pf][cf], 0, 0, 0);
+            }
+            if constexpr (NPL >= 2) {
+              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[1], acc[pf][cf], 0, 0, 0);
+              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[0], acc[pf][cf], 0, 0, 0);
+            }
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[0], acc[pf][cf], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if ((p.ablate & 8) && !next_a) { t = tn; c = cn; g = gn; goff_cur = goff_next; continue; }
+      // every wave has read this step's fragments — not needed for the weight tile alone when it goes to the other
+      // image (its last readers finished before the barrier that ended the previous step)
+      if (!p.bdouble || next_a) __syncthreads();
+      // 3. commit the staged data
+      if (next_b && !(p.ablate & 2)) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) b_store(breg[q], q, (gstep + 1) & 1);
+      }
+      if (next_a && !(p.ablate & 2)) {
+        const int ppx = opaque(pp);
+#pragma unroll
+        for (int j = 0; j < MAXPF; ++j)
+          if (j < p.npass) a_store(a_desc(j, goff_next, T, ppx), areg[j]);
+        a_stage_sync(MAXPF, cn * KC, goff_next, T);  // more than MAXPF passes: the rest without prefetch
+      }
+      __syncthreads();
+      if (gn != g && !last) { seg_lo = seg_hi; seg_hi = p.seg_begin[gn + 1]; }
+      t = tn; c = cn; g = gn; goff_cur = goff_next;
+    }
+
+    // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -----------------------------
+    // (the stores are not waited for: they drain while the next tile's first steps run)
+    const int n0 = cur.n0;
+    const float* bias_c = p.bias ? p.bias + (size_t)cur.client * p.bias_client_stride : nullptr;
+    f32x4 st_s[4], st_q[4];
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) { st_s[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; st_q[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int pf = 0; pf < MF; ++pf) {
+      const int m = (wave * MF + pf) * 16 + li;
+      const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
+      const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
+      if (!(il < p.TI && cur.sy0 + ry < p.Hs && cur.img0 + il < p.N)) continue;
+      const long out_pix = ((long)(cur.img0 + il) * p.Hout + (cur.sy0 + ry) * p.so + p.poy) * p.Wout + sx * p.so + p.pox;
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) {
+        const int co = n0 + cf * 16 + kg * 4;
+        if (co >= p.Co) continue;
+        f32x4 v = acc[pf][cf];
+        if (bias_c != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? bias_c[co + j] : 0.f;
+        }
+        if (want_stats) { st_s[cf] += v; st_q[cf] += v * v; }
+        if constexpr (SPLIT) {
+          float* dst = reinterpret_cast<float*>(p.out) + out_pix * p.Co + co;
+          if (vec_out) {
+            if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = v;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+          }
+        } else {
+          unsigned short* dst = reinterpret_cast<unsigned short*>(p.out) + out_pix * p.Co + co;
+          if (p.accumulate) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (co + j < p.Co) v[j] += __uint_as_float((unsigned)dst[j] << 16);
+          }
+          const u32x2 b = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+          if (vec_out) *reinterpret_cast<u32x2*>(dst) = b;
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = (unsigned short)(b[j >> 1] >> ((j & 1) * 16));
+          }
         }
       }
     }
-  }
-  if constexpr (SPLIT) {
-    if (want_stats) {
-      // BatchNorm statistics of this tile: fixed-order tree over the 16 pixel lanes, then over the four waves
-      // through LDS (every wave is past its last fragment read: the K loop ends with a barrier)
-#pragma unroll
-      for (int cf = 0; cf < 4; ++cf)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) {
-            st_s[cf][j] += __shfl_xor(st_s[cf][j], o);
-            st_q[cf][j] += __shfl_xor(st_q[cf][j], o);
-          }
-      float* red = reinterpret_cast<float*>(smem);  // [4 waves][64 ch][2]
-      if (li == 0) {
+    if constexpr (SPLIT) {
+      if (want_stats) {
+        // BatchNorm statistics of this tile: fixed-order tree over the 16 pixel lanes, then over the four waves
+        // through an LDS scratch of its own (the input image already holds the next tile's first chunk).  The
+        // scratch's previous readers are at least one K step, i.e. one barrier, behind.
 #pragma unroll
         for (int cf = 0; cf < 4; ++cf)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int ch = cf * 16 + kg * 4 + j;
-            red[(wave * 64 + ch) * 2 + 0] = st_s[cf][j];
-            red[(wave * 64 + ch) * 2 + 1] = st_q[cf][j];
-          }
-      }
-      __syncthreads();
-      if (tid < 128) {
-        const int ch = tid >> 1, which = tid & 1;
-        if (n0 + ch < p.Co) {
-          float a = 0.f;
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int w = 0; w < 4; ++w) a += red[(w * 64 + ch) * 2 + which];
-          const int cl = img0 / p.stats_B, in_cl = img0 - cl * p.stats_B;
-          const int chunk = p.TI == 1 ? in_cl * p.tiles_per_img + (mt - img0 * p.tiles_per_img) : in_cl / p.TI;
-          p.stats[(((size_t)cl * p.stats_nchunk + chunk) * p.Co + n0 + ch) * 2 + which] = a;
+            for (int o = 1; o < 16; o <<= 1) {
+              st_s[cf][j] += __shfl_xor(st_s[cf][j], o);
+              st_q[cf][j] += __shfl_xor(st_q[cf][j], o);
+            }
+        if (li == 0) {
+#pragma unroll
+          for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ch = cf * 16 + kg * 4 + j;
+              red[(wave * 64 + ch) * 2 + 0] = st_s[cf][j];
+              red[(wave * 64 + ch) * 2 + 1] = st_q[cf][j];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+          const int ch = tid >> 1, which = tid & 1;
+          if (n0 + ch < p.Co) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += red[(w * 64 + ch) * 2 + which];
+            const int cl = cur.img0 / p.stats_B, in_cl = cur.img0 - cl * p.stats_B;
+            const int chunk = p.TI == 1 ? in_cl * p.tiles_per_img + (cur.mt - cur.img0 * p.tiles_per_img) : in_cl / p.TI;
+            p.stats[(((size_t)cl * p.stats_nchunk + chunk) * p.Co + n0 + ch) * 2 + which] = a;
+          }
         }
       }
     }
+    if (!has_next) break;
+    lid = lid_next;
+    cur = nxt;
   }
 }
 
@@ -499,7 +561,7 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
       const int rows = q.TI > 1 ? (q.TI - 1) * (q.IR - share) + q.IR : q.IR;
       q.IS = q.TI > 1 ? (q.IR - share) * p.WS : q.IR * p.WS;
       q.NS = round_up(rows * p.WS + hpad + p.PL + 1, 4);
-      long lds = (long)npl * q.NS * 64 + 2L * npl * BN * 64;
+      long lds = (long)npl * q.NS * 64 + 2L * npl * BN * 64 + RED_BYTES;
       q.bdouble = 1;
       if (lds > LDS_TOTAL / wgs_per_cu(mf) || no_bdouble()) { lds -= (long)npl * BN * 64; q.bdouble = 0; }
       q.region_px = q.TI * q.IR * p.Wi;
@@ -529,7 +591,7 @@ int stats_chunks(const IgemmParams& p, int B) {
 
 template <int NPL, int MF, bool SPLIT>
 int launch(const IgemmParams& p, hipStream_t st) {
-  const size_t lds = (size_t)NPL * p.NS * 64 + (size_t)(p.bdouble ? 2 : 1) * NPL * BN * 64;
+  const size_t lds = (size_t)NPL * p.NS * 64 + (size_t)(p.bdouble ? 2 : 1) * NPL * BN * 64 + RED_BYTES;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<NPL, MF, SPLIT>),
@@ -537,7 +599,18 @@ int launch(const IgemmParams& p, hipStream_t st) {
     attr = true;
   }
   const int blocks = p.n_mtiles * p.n_ntiles;
-  const int grid = (blocks + 7) / 8 * 8;
+  // persistent tiles: at most the resident workgroups (BLADES_IGEMM_GRID: another cap — tests walk many tiles per
+  // workgroup on small problems with it; 0 = one workgroup per tile, the pre-persistent behaviour)
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  const char* e = getenv("BLADES_IGEMM_GRID");
+  int cap = e ? atoi(e) : cus * wgs_per_cu(MF);
+  cap = cap <= 0 ? 0 : (cap + 7) / 8 * 8;
+  int grid = (blocks + 7) / 8 * 8;
+  if (cap > 0 && grid > cap) grid = cap;
   hipLaunchKernelGGL((conv_igemm_kernel<NPL, MF, SPLIT>), dim3(grid), dim3(256), lds, st, p);
   return 0;
 }
@@ -621,6 +694,25 @@ BLADES_API long blades_conv_igemm_ws(int Co, int Ci, int kh, int kw, int mode, i
   return (long)(n_clients < 1 ? 1 : n_clients) * npl * kh * kw * round_up(rows, BN) * round_up(k, KC) * 2;
 }
 
+// Weight planes of one layer: `ws` (blades_conv_igemm_ws bytes) <- split / transposed / padded copy of `w`.  The
+// FedSGD engine calls this once per layer and round (the weights are constant while the clients train) and hands
+// the planes to every chunk's blades_conv_igemm2(..., flags & 1).
+BLADES_API int blades_conv_wprep(const float* w, void* ws, int Co, int Ci, int kh, int kw, int mode, int npl,
+                                 int n_clients, long w_client_stride, hipStream_t st) {
+  if (npl < 1 || npl > 3 || kh * kw > MAXTAPS) return 1;
+  if (n_clients < 1) n_clients = 1;
+  if (n_clients > 65535) return 5;
+  const int taps = kh * kw;
+  const int rows = mode == 0 ? Co : Ci, k = mode == 0 ? Ci : Co;
+  const int rows_pad = round_up(rows, BN), k_pad = round_up(k, KC);
+  const size_t total = (size_t)taps * rows_pad * k_pad;
+  int gx = cdiv((long)total, 256);
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(conv_wprep_kernel, dim3(gx, n_clients), dim3(256), 0, st, w, (unsigned short*)ws, Co, Ci, taps,
+                     rows, rows_pad, k, k_pad, mode, npl, w_client_stride);
+  return 0;
+}
+
 // mode 0: forward    in = x  [N,H,W,Ci]   -> out = y  [N,Ho,Wo,Co]   (bias optional)
 // mode 1: data grad  in = gy [N,Ho,Wo,Co] -> out = dx [N,H,W,Ci]
 // w: [Co][Ci][kh][kw] fp32 contiguous.  npl 3 / 2: fp32 tensors; npl 1: bf16 tensors.
@@ -628,11 +720,12 @@ BLADES_API long blades_conv_igemm_ws(int Co, int Ci, int kh, int kw, int mode, i
 // w + client * w_client_stride (bias + client * bias_client_stride); the FedSGD fast path passes n_clients = 1.
 // stats != null (forward, fp32 tensors): also writes the per-client BatchNorm partial sums of the output,
 // [N / stats_B clients][blades_conv_igemm_stats_nchunk(...) chunks][Co][2] floats.
+// flags: 1 = `ws` already holds this layer's planes (blades_conv_wprep; `w` is not read); 2 = out += result.
 // returns 0 ok; nonzero = unsupported (caller falls back)
-BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
-                                 int W, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad, int mode,
-                                 int npl, int n_clients, long w_client_stride, long bias_client_stride,
-                                 float* stats, int stats_B, hipStream_t st) {
+BLADES_API int blades_conv_igemm2(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
+                                  int W, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad, int mode,
+                                  int npl, int n_clients, long w_client_stride, long bias_client_stride,
+                                  float* stats, int stats_B, int flags, hipStream_t st) {
   if (npl < 1 || npl > 3 || kh * kw > MAXTAPS || stride < 1 || N <= 0) return 1;
   if (n_clients < 1) n_clients = 1;
   if (N % n_clients || n_clients > 65535) return 5;
@@ -640,12 +733,9 @@ BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bi
   const int taps = kh * kw;
   const int rows = mode == 0 ? Co : Ci, k = mode == 0 ? Ci : Co;
   const int rows_pad = round_up(rows, BN), k_pad = round_up(k, KC);
-  {
-    const size_t total = (size_t)taps * rows_pad * k_pad;
-    int gx = cdiv((long)total, 256);
-    if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(conv_wprep_kernel, dim3(gx, n_clients), dim3(256), 0, st, w, (unsigned short*)ws, Co, Ci, taps,
-                       rows, rows_pad, k, k_pad, mode, npl, w_client_stride);
+  if (!(flags & 1)) {
+    const int rc = blades_conv_wprep(w, ws, Co, Ci, kh, kw, mode, npl, n_clients, w_client_stride, st);
+    if (rc != 0) return rc;
   }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -653,6 +743,7 @@ BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bi
   p.N = N; p.ntw = taps; p.Cop = rows_pad; p.Cip = k_pad;
   p.n_clients = n_clients; p.imgs_per_client = N / n_clients;
   p.wp_client_stride = (long)npl * taps * rows_pad * k_pad; p.bias_client_stride = bias_client_stride;
+  p.accumulate = (flags & 2) ? 1 : 0;
   int ay[MAXTAPS], ax[MAXTAPS];
   p.in_rm = p.in_cm = 1;
   if (mode == 0) {
@@ -680,10 +771,19 @@ BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bi
         }
       }
       q.ntaps = n;
+      if (n == 0 && q.accumulate) continue;  // no tap reaches this parity class: nothing to add
       const int rc = dispatch(q, npl, ay, ax, st);
       if (rc != 0) return rc;
     }
   return 0;
+}
+
+BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
+                                 int W, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad, int mode,
+                                 int npl, int n_clients, long w_client_stride, long bias_client_stride,
+                                 float* stats, int stats_B, hipStream_t st) {
+  return blades_conv_igemm2(in, w, bias, out, ws, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, mode, npl, n_clients,
+                            w_client_stride, bias_client_stride, stats, stats_B, 0, st);
 }
 
 // Chunks per client of the BatchNorm partial sums a forward call with `stats` writes; 0 = not available for this

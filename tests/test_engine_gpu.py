@@ -203,3 +203,27 @@ def test_local_steps_fused_per_client_matches_cpu_oracle(tmp_path, model, ds):
     assert float(rel.median()) < 2e-2 and float(rel.max()) < 1e-1 and float(cos.min()) > 0.995, (rel, cos)
     if model != "resnet":  # no ReLU behind a strided convolution chain: these stay tight
         assert float(rel.max()) < 1e-3, rel
+
+
+@pytest.mark.parametrize("model", ["resnet", "resnet18"])
+def test_round_planes_and_gradient_join_are_bitwise_neutral(tmp_path, model):
+    """Two round-3 changes of the fused executor that must not change a bit of the update matrix: the weight planes
+    split once per round (instead of per chunk and launch), and the residual blocks' input gradient summed in the
+    data-gradient kernel's epilogue (GradJoin) instead of by a separate add — the same two fp32 operands either way."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    keys = ("BLADES_ROUND_PLANES", "BLADES_GRAD_JOIN")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        os.environ["BLADES_ROUND_PLANES"], os.environ["BLADES_GRAD_JOIN"] = "1", "1"
+        U_new, loss_new, _ = _run(tmp_path, "0", "cifar10", model, "ALIEAdversary", rounds=3, server_lr=0.05, chunk=3)
+        os.environ["BLADES_ROUND_PLANES"], os.environ["BLADES_GRAD_JOIN"] = "0", "0"
+        U_old, loss_old, _ = _run(tmp_path, "0", "cifar10", model, "ALIEAdversary", rounds=3, server_lr=0.05, chunk=3)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert loss_new == loss_old
+    assert torch.equal(U_new, U_old)

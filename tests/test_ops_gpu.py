@@ -396,6 +396,102 @@ def test_conv_igemm_kernel(dev, N, Ci, H, W, Co, k, s, p, npl):
     torch.testing.assert_close(dx.double().cpu(), dx_ref, rtol=tol, atol=tol * float(dx_ref.abs().max()))
 
 
+@pytest.mark.parametrize("N,Ci,H,W,Co,k,s,p,B", [
+    (24, 64, 32, 32, 64, 3, 1, 1, 4), (12, 64, 32, 32, 128, 3, 2, 1, 3), (12, 64, 32, 32, 128, 1, 2, 0, 3),
+    (40, 128, 16, 16, 128, 3, 1, 1, 5), (72, 256, 8, 8, 256, 3, 1, 1, 8), (96, 512, 4, 4, 512, 3, 1, 1, 16),
+    (24, 32, 32, 32, 64, 1, 1, 0, 4), (14, 20, 9, 9, 24, 5, 1, 2, 7),
+])
+@pytest.mark.parametrize("npl", [3, 1])
+@pytest.mark.parametrize("grid", [8, 16])
+def test_conv_igemm_persistent_tiles(dev, monkeypatch, N, Ci, H, W, Co, k, s, p, B, npl, grid):
+    """A workgroup of conv_igemm walks several tiles (grid capped at 8 / 16 workgroups here; 512 on the bench): the next
+    tile's first input chunk / weight tile are staged behind the previous tile's last step, rows that were image
+    rows for one tile are padding for the next, the BatchNorm partial sums use their own LDS scratch.  Forward (with
+    statistics), data gradient and its accumulate mode against fp64."""
+    import torch.nn.functional as F
+    from blades_amd import ops
+
+    h = ops._h()
+    monkeypatch.setenv("BLADES_IGEMM_GRID", str(grid))
+    g = torch.Generator().manual_seed(N * 1000 + Ci + grid)
+    dt = torch.bfloat16 if npl == 1 else torch.float32
+    x = torch.randn(N, Ci, H, W, generator=g).to(dt)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = (w.to(dt) if npl == 1 else w).double()
+    y_ref = F.conv2d(xr, wr, b.double(), s, p)
+    gy = torch.randn(y_ref.shape, generator=g).to(dt)
+    dx_ref, = torch.autograd.grad(y_ref, xr, gy.double())
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    gyd = gy.to(dev).contiguous(memory_format=torch.channels_last)
+    wd, bd = w.to(dev), b.to(dev)
+    tol = {3: 1e-5, 1: 2e-2}[npl]
+    if npl == 3:
+        y, pre = h.conv_forward(xd, wd, bd, s, p, npl, stats_B=B)
+        if pre is not None:
+            part, nch = pre
+            st = part.view(N // B, nch, Co, 2).double().sum(1).cpu()
+            yr = y_ref.detach().reshape(N // B, B, Co, -1)
+            torch.testing.assert_close(st[..., 0], yr.sum(dim=(1, 3)), rtol=1e-4, atol=1e-3)
+            torch.testing.assert_close(st[..., 1], (yr * yr).sum(dim=(1, 3)), rtol=1e-4, atol=1e-3)
+    else:
+        y = h.conv_forward(xd, wd, bd, s, p, npl)
+    torch.testing.assert_close(y.double().cpu(), y_ref.detach(), rtol=tol, atol=tol * float(y_ref.abs().max()))
+    dx = h.conv_dgrad(gyd, wd, (H, W), s, p, npl)
+    torch.testing.assert_close(dx.double().cpu(), dx_ref, rtol=tol, atol=tol * float(dx_ref.abs().max()))
+    # ready-made weight planes (one split per round) give the same bits as the per-call split
+    y2 = h.conv_forward(xd, wd, bd, s, p, npl, planes=h.conv_planes(wd, 0, npl))
+    dx2 = h.conv_dgrad(gyd, wd, (H, W), s, p, npl, planes=h.conv_planes(wd, 1, npl))
+    assert torch.equal(y2, y) and torch.equal(dx2, dx)
+    # accumulate mode: the other gradient branch of a residual block is added in the epilogue
+    other = torch.randn(N, Ci, H, W, generator=g).to(dt)
+    acc = other.to(dev).contiguous(memory_format=torch.channels_last)
+    out = h.conv_dgrad(gyd, wd, (H, W), s, p, npl, accumulate_into=acc)
+    assert out.data_ptr() == acc.data_ptr()
+    ref = dx_ref + other.double()
+    torch.testing.assert_close(out.double().cpu(), ref, rtol=tol, atol=tol * float(ref.abs().max()) * (4 if npl == 1 else 1))
+
+
+@pytest.mark.parametrize("Kc,B,Ci,H,W,Co,k,s,p", [
+    (3, 4, 64, 32, 32, 64, 3, 1, 1), (5, 3, 64, 16, 16, 128, 3, 2, 1), (4, 6, 128, 8, 8, 128, 3, 1, 1),
+    (3, 8, 256, 4, 4, 256, 3, 1, 1), (7, 5, 64, 8, 8, 128, 1, 2, 0), (2, 12, 32, 4, 4, 64, 3, 1, 1),
+])
+@pytest.mark.parametrize("grid", [0, 8])
+def test_conv_igemm_per_client_weights(dev, monkeypatch, Kc, B, Ci, H, W, Co, k, s, p, grid):
+    """Per-client weight sets (local steps > 1): image n uses client n // B's weights and bias, taken as rows of a
+    wider strided matrix like the engine's W.  Forward and data gradient against a per-client fp64 convolution
+    (B not a power of two, 4x4 / 8x8 maps, stride 2, several tiles per workgroup)."""
+    import torch.nn.functional as F
+    from blades_amd import ops
+
+    h = ops._h()
+    if grid:
+        monkeypatch.setenv("BLADES_IGEMM_GRID", str(grid))
+    g = torch.Generator().manual_seed(Kc * 100 + Ci)
+    nw = Co * Ci * k * k
+    Wm = torch.randn(Kc, 11 + nw + Co + 5, generator=g) / (Ci * k * k) ** 0.5  # rows of a wider matrix
+    x = torch.randn(Kc * B, Ci, H, W, generator=g)
+    Wd = Wm.to(dev)
+    w5 = Wd.as_strided((Kc, Co, Ci, k, k), (Wd.stride(0), Ci * k * k, k * k, k, 1), 11)
+    b2 = Wd.as_strided((Kc, Co), (Wd.stride(0), 1), 11 + nw)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    y = h.conv_forward(xd, w5, b2, s, p, 3)
+    Ho, Wo = y.shape[2], y.shape[3]
+    gy = torch.randn(Kc * B, Co, Ho, Wo, generator=g)
+    dx = h.conv_dgrad(gy.to(dev).contiguous(memory_format=torch.channels_last), w5, (H, W), s, p, 3)
+    for c in range(Kc):
+        wc = Wm[c, 11: 11 + nw].reshape(Co, Ci, k, k).double()
+        bc = Wm[c, 11 + nw: 11 + nw + Co].double()
+        xc = x[c * B: (c + 1) * B].double().requires_grad_(True)
+        yr = F.conv2d(xc, wc, bc, s, p)
+        dr, = torch.autograd.grad(yr, xc, gy[c * B: (c + 1) * B].double())
+        torch.testing.assert_close(y[c * B: (c + 1) * B].double().cpu(), yr.detach(), rtol=1e-5,
+                                   atol=1e-5 * float(yr.abs().max()))
+        torch.testing.assert_close(dx[c * B: (c + 1) * B].double().cpu(), dr, rtol=1e-5,
+                                   atol=1e-5 * float(dr.abs().max()))
+
+
 @pytest.mark.parametrize("N,C", [(1, 10), (300, 10), (1000, 10), (257, 100), (64, 3)])
 def test_ce_topk(dev, N, C):
     from blades_amd import ops
