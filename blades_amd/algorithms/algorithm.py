@@ -64,6 +64,9 @@ class Algorithm:
         result["rounds_per_s"] = 1.0 / dt if dt > 0 else float("inf")
         if self._result_logger is not None:
             self._result_logger.on_result(result)
+        from blades_amd.parallel.runtime import heartbeat
+
+        heartbeat(f"iteration {self._iteration} done")  # (after evaluation and result logging: still alive)
         return result
 
     def step(self) -> ResultDict:

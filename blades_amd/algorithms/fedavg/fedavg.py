@@ -249,7 +249,8 @@ class Fedavg(Algorithm):
         self._counters[NUM_GLOBAL_STEPS] += 1
         global_vars = {"timestep": self._counters[NUM_GLOBAL_STEPS]}
         with T("aggregate_and_step"):
-            server_return = self.server.step(U, global_vars)
+            server_return = self.server.step(U, global_vars, owned=True)
+        self._check_replicas()
         stats = torch.stack([loss_sum, loss_cnt]).tolist()  # the round's single host sync
         results = {"train_loss": stats[0] / stats[1] if stats[1] > 0 else float("nan")}
         results.update(server_return)
@@ -265,6 +266,30 @@ class Fedavg(Algorithm):
         if info and "num_selected" in info:
             results["num_selected_clients"] = int(info["num_selected"])
         return results
+
+    def _check_replicas(self):
+        """"allgather" layout: every rank aggregates the full matrix on its own and steps its own copy of theta, so
+        the replicas stay equal only while every adversary / aggregator path is bitwise identical on all ranks (host
+        clustering, library solver choices).  Every ``BLADES_REPLICA_CHECK_EVERY`` rounds (default 16; 0 = never)
+        the copies are compared (max - min of theta over ranks, one all-reduce of D floats each) and a fork raises
+        instead of silently training different models."""
+        if self.update_layout != "allgather" or not self.rt.distributed:
+            return
+        import os
+
+        every = int(os.environ.get("BLADES_REPLICA_CHECK_EVERY", "16"))
+        n = self._counters[NUM_GLOBAL_STEPS]
+        if every <= 0 or n % every:
+            return
+        import torch.distributed as dist
+
+        th = self.server.theta.detach()
+        hi, lo = th.clone(), th.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        spread = float((hi - lo).abs().max())
+        if not spread == 0.0:  # (NaN on some rank only also lands here)
+            raise RuntimeError(f"replicated theta diverged across ranks after round {n}: max |difference| = {spread}")
 
     # -- fault injection / detection (SURVEY §5.3) ---------------------------
     def _fault_events(self):
@@ -324,8 +349,14 @@ class Fedavg(Algorithm):
             U[bad] = 0.0
 
     def evaluate(self):
+        from blades_amd.parallel.runtime import heartbeat
+
+        # progress marks for the launcher's stall watchdog around the phases that are not a training round (the
+        # engine marks every evaluation chunk as well): a long evaluation or checkpoint is work, not a hang
+        heartbeat(f"evaluate {self.engine.round}")
         with self._timers("evaluate"):
             r = self.engine.evaluate(self.server.theta)
+        heartbeat(f"evaluated {self.engine.round}")
         # reference returns ce_loss + acc_top_1 (fedavg.py:268-277); the other top-k accuracies of its Task
         # metric collection (task.py:104-121) come out of the same fused kernel for free
         return {k: v for k, v in r.items() if k == "ce_loss" or k.startswith("acc_top_")}
@@ -355,7 +386,13 @@ class Fedavg(Algorithm):
             np.random.set_state(state["numpy_rng"])
 
     def save_checkpoint(self, checkpoint_dir: str) -> str:
-        if self.rt.is_main:
-            return super().save_checkpoint(checkpoint_dir)
-        self.__getstate__()  # collectives inside state_dict must run on every rank
-        return checkpoint_dir
+        from blades_amd.parallel.runtime import heartbeat
+
+        heartbeat(f"checkpoint {self.engine.round}")
+        try:
+            if self.rt.is_main:
+                return super().save_checkpoint(checkpoint_dir)
+            self.__getstate__()  # collectives inside state_dict must run on every rank
+            return checkpoint_dir
+        finally:
+            heartbeat(f"checkpointed {self.engine.round}")

@@ -76,9 +76,23 @@ class DropContext:
         self.Kc = 0
         self.tag = torch.zeros(1, dtype=torch.int64, device=device)  # round * nb + step, on the device: a captured
         self.enabled = True                                          # HIP graph reads the current value
+        self._tags = {}
 
     def set(self, uids: torch.Tensor, layout: str):
         self.uids, self.layout, self.Kc = uids, layout, (int(uids.numel()) if uids.dim() else 1)
+
+    def bind(self, key) -> None:
+        """Makes ``tag`` the device scalar that belongs to chunk ``key``.  The dropout kernels read the tag when they
+        *execute*; chunks run on several HIP streams (and, with several local steps, at different step numbers at
+        the same time), so a scalar shared by all chunks would be overwritten by one chunk's ``set_tag`` while
+        another chunk's kernels are still queued.  Every chunk therefore fills and reads a scalar of
+        its own, which also lives as long as any HIP graph captured for that chunk."""
+        t = self._tags.get(key)
+        if t is None:
+            if len(self._tags) > 8192:
+                self._tags.clear()  # (tensors referenced by live graphs stay alive through the graphs' keep lists)
+            t = self._tags[key] = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.tag = t
 
     def set_tag(self, value: int):
         self.tag.fill_(int(value))

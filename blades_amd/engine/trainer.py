@@ -382,6 +382,9 @@ class ClientEngine:
             return None  # eager first: wgrad plan tables (host->device copies) and library kernel searches happen
             # outside capture; the split-K scratch is a per-graph temporary (ops/_hip.py::_scratch)
         Kc = len(rows)
+        # the chunk's own dropout tag (captured by address, filled before every replay): engine/layers.py DropContext.bind
+        self.drop_ctx.bind((b"f",) + key)
+        ent["tag"] = self.drop_ctx.tag
         if ent["graph"] is None:
             any_flip = self._any_flip
             dev_rows = self.sampler.rows_on_device(srows)
@@ -447,6 +450,7 @@ class ClientEngine:
         gscale, flip, gclip = self._row_vectors(rows)
         X, Y = self._fetch_batch(srows, flip)
         uids_t = self._chunk_uids(srows)
+        self.drop_ctx.bind((b"e", rows.tobytes()))
         self.drop_ctx.set_tag(self._drop_tag())
         self.drop_ctx.set(uids_t, "major")
         rows_t = self._chunk_consts(rows)[0]
@@ -520,6 +524,8 @@ class ClientEngine:
         Kc = len(rows)
         srows_t = torch.as_tensor(srows, device=self.device)
         rows_t = torch.as_tensor(rows, device=self.device)
+        self.drop_ctx.bind(key)  # the chunk's own dropout tag: captured by address, filled before every replay
+        ent["tag"] = self.drop_ctx.tag
         if ent["graph"] is None:
             any_flip = self._any_flip
             dev_rows = self.sampler.rows_on_device(srows)
@@ -602,6 +608,7 @@ class ClientEngine:
             self._local_step = step
             X, Y = self._fetch_batch(srows, flip)
             uids_t = self._chunk_uids(srows)
+            self.drop_ctx.bind((b"e", rows.tobytes()))
             self.drop_ctx.set_tag(self._drop_tag())
             losses = None
             if self.fused_pc:
@@ -922,6 +929,8 @@ class ClientEngine:
     # ------------------------------------------------------------------
     @torch.no_grad()
     def evaluate(self, theta: torch.Tensor) -> Dict[str, float]:
+        from blades_amd.parallel.runtime import heartbeat as _heartbeat
+
         """All clients' test shards (malicious ones too, like the reference),
         batches of ``test_bs`` with batch-statistics BN; length-weighted means."""
         theta = theta.detach()[: self.D]
@@ -949,6 +958,7 @@ class ClientEngine:
             if n == 0:
                 continue
             for c0 in range(0, len(rs), self.eval_chunk):
+                _heartbeat(f"evaluate chunk {c0}")
                 rr = rs[c0: c0 + self.eval_chunk]
                 offs = torch.as_tensor(st.offsets[rr], device=self.device)
                 for b0 in range(0, n, bs):

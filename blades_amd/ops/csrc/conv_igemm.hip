@@ -54,7 +54,6 @@ constexpr int BN = 64;        // output channels per workgroup
 constexpr int MAXTAPS = 25;
 constexpr int MAXSEG = 16;    // reduction segments (input parity classes of a strided forward convolution)
 constexpr int LDS_TOTAL = 160 * 1024;
-constexpr int RED_BYTES = 4 * 64 * 2 * 4;  // epilogue scratch of the BatchNorm partial sums: [4 waves][64 ch][2]
 // two workgroups per CU (<= 80 KB LDS, <= 256 registers each); three smaller ones measured slower (MF = 2: 5.7 vs
 // 5.2 ms on the 64-channel layer: the weight-fragment reads per MFMA double)
 constexpr int wgs_per_cu(int) { return 2; }
@@ -77,6 +76,7 @@ struct IgemmParams {
   int tap_w[MAXTAPS];         // index of tap t in the weight tensor
   int n_clients, imgs_per_client;  // per-client weights (local steps > 1): image n uses weight set n / imgs_per_client
   long wp_client_stride, bias_client_stride;  // elements between two clients' weight planes / biases
+  unsigned long long* prof;   // PROF build: [16] cycle sums (see the kernel)
   int ablate;                 // diagnostics (BLADES_IGEMM_ABLATE): 1 no staging loads, 2 no commit, 4 no MFMAs
   int bdouble;                // two weight-tile images in LDS (where they fit): a step's successor tile is committed
                               // without waiting for the other waves, one barrier per step instead of two
@@ -106,52 +106,41 @@ __device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NPL]) {
   }
 }
 
-template <int NPL, int MF, bool SPLIT>
+// PROF (diagnostic build of one variant, BLADES_IGEMM_PROF=1): s_memtime stamps at the phase boundaries of every
+// wave, summed over the launch into p.prof[16] — where a workgroup's time goes (tools/r3/igemm_prof.py)
+template <int NPL, int MF, bool SPLIT, bool PROF = false>
 __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const IgemmParams p) {
   static_assert(SPLIT || NPL == 1, "bf16 input has a single plane");
+  unsigned long long pf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_last = 0;  // (constant indices only: scalar registers)
+  auto stamp = [&](const int slot) {
+    if constexpr (PROF) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      pf_t[slot] += now - pf_last;
+      pf_last = now;
+    }
+  };
+  if constexpr (PROF) pf_last = __builtin_amdgcn_s_memtime();
   constexpr int MAXPF = max_prefetch(MF);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // Persistent tiles.  The grid holds at most the workgroups that are resident at once (two per CU); a workgroup
-  // walks the tiles lid, lid + stride, ... of its XCD's contiguous tile range (neighbouring tiles share halo rows,
-  // all channel tiles of a pixel tile share the input through that XCD's L2).  A tile boundary is treated like a
-  // chunk boundary of the K loop: the next tile's first weight tile and first input chunk are fetched under the
-  // last step's MFMAs and committed behind it, the finished tile's stores drain under the next tile's MFMAs, so
-  // neither the prologue's load latency nor the epilogue's store burst is exposed once per tile (they were: all
-  // workgroups of a launch start together and stay in phase, the chip alternated between an HBM phase and an MFMA
-  // phase).
-  const int ntiles = p.n_mtiles * p.n_ntiles;
-  const int wg_per_xcd = gridDim.x >> 3;  // the grid is a multiple of 8
-  const int tiles_per_xcd = (ntiles + 7) >> 3;
-  const int tile_lo = (blockIdx.x & 7) * tiles_per_xcd;
-  const int tile_hi = tile_lo + tiles_per_xcd < ntiles ? tile_lo + tiles_per_xcd : ntiles;
-  int lid = tile_lo + (blockIdx.x >> 3);
-  if (lid >= tile_hi) return;  // whole workgroup leaves: no barrier is skipped by a subset
-
-  struct Tile {
-    int n0, img0, sy0, mt, client;
-    __device__ __forceinline__ int iy_lo(const IgemmParams& p) const { return sy0 * p.si + p.aymin; }
-    // per-client weights: a tile never straddles two clients (plan() keeps TI a divisor of imgs_per_client)
-    __device__ __forceinline__ const unsigned short* wp(const IgemmParams& p) const {
-      return p.wp + (size_t)client * p.wp_client_stride;
-    }
-  };
-  auto tile_ctx = [&](int id) {
-    Tile T;
-    const int nt = id % p.n_ntiles;
-    T.mt = id / p.n_ntiles;
-    T.n0 = nt * BN;
-    if (p.TI == 1) { T.img0 = T.mt / p.tiles_per_img; T.sy0 = (T.mt - T.img0 * p.tiles_per_img) * p.TR; }
-    else { T.img0 = T.mt * p.TI; T.sy0 = 0; }
-    T.client = p.n_clients > 1 ? T.img0 / p.imgs_per_client : 0;
-    return T;
-  };
+  const int per_xcd = gridDim.x >> 3;
+  const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (lid >= p.n_mtiles * p.n_ntiles) return;  // whole workgroup leaves: no barrier is skipped by a subset
+  const int nt = lid % p.n_ntiles, mt = lid / p.n_ntiles;
+  const int n0 = nt * BN;
+  int img0, sy0;
+  if (p.TI == 1) { img0 = mt / p.tiles_per_img; sy0 = (mt - img0 * p.tiles_per_img) * p.TR; }
+  else { img0 = mt * p.TI; sy0 = 0; }
+  const int iy_lo = sy0 * p.si + p.aymin;
+  // per-client weights: a tile never straddles two clients (plan() keeps TI a divisor of imgs_per_client)
+  const int client = p.n_clients > 1 ? img0 / p.imgs_per_client : 0;
+  const unsigned short* wp_c = p.wp + (size_t)client * p.wp_client_stride;
+  const float* bias_c = p.bias ? p.bias + (size_t)client * p.bias_client_stride : nullptr;
 
   const int a_plane = p.NS * 64, a_buf = NPL * a_plane;
   constexpr int b_plane = BN * 64;
   unsigned char* A_lds = smem;          // [NPL][NS slots][32 ch] bf16
   unsigned char* B_lds = smem + a_buf;  // [NPL][64 co][32 ci] bf16
-  // zero fill, once: the slots no staging pass ever writes (horizontal padding between rows) stay zero for every tile
   for (int i = tid * 16; i < a_buf; i += 256 * 16) *reinterpret_cast<u32x4*>(A_lds + i) = u32x4{0, 0, 0, 0};
 
   // Both LDS images have 64-byte rows (32 channels of one slot / one output channel).  A fragment read
@@ -160,25 +149,34 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   // makes those reads conflict-free.  Stores apply the same involution.
   auto swz = [](int row) { return (row & 4) << 3; };
 
+  // ---- this lane's output pixels: fragment pf, column li ---------------------------------------------------
   const int li = lane & 15, kg = lane >> 4;
+  int a_slot[MF];
+  long out_pix[MF];
+#pragma unroll
+  for (int pf = 0; pf < MF; ++pf) {
+    const int m = (wave * MF + pf) * 16 + li;
+    const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
+    const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
+    const bool ok = il < p.TI && sy0 + ry < p.Hs && img0 + il < p.N;
+    a_slot[pf] = ok ? il * p.IS + ry * p.si * p.WS + sx * p.si + p.PL : p.PL;
+    out_pix[pf] = ok ? ((long)(img0 + il) * p.Hout + (sy0 + ry) * p.so + p.poy) * p.Wout + sx * p.so + p.pox : -1;
+  }
 
   // ---- staging roles -----------------------------------------------------------------------------------------
   // A: one pass = PIXPP region pixels x 32 channels; lane group (cg) covers CPL channels of a pixel (16 bytes)
   constexpr int CPL = SPLIT ? 4 : 8, LPP = KC / CPL, PIXPP = 256 / LPP;
   const int cg = tid % LPP, pp = tid / LPP;
-  struct ADesc { long goff; int slot; };  // goff < 0: nothing to load (the slot gets zeros); slot < 0: not a slot
-  // (`ppx`: the thread's pixel index within a pass, handed in through an opaque copy at every staging site — the
-  // descriptors of all passes are invariant per lane and the compiler otherwise keeps them, three dozen registers,
-  // alive through the whole K loop)
-  auto a_desc = [&](int pass, long seg_goff, const Tile& T, int ppx) {
+  struct ADesc { long goff; int slot; };
+  auto a_desc = [&](int pass, long seg_goff) {
     ADesc d;
-    const int e = pass * PIXPP + ppx;
+    const int e = pass * PIXPP + pp;
     const int il = fdiv(e, p.inv_irwi), rem = e - il * p.IR * p.Wi;
     const int r = fdiv(rem, p.inv_wi), ix = rem - r * p.Wi;
-    const int iy = T.iy_lo(p) + r;
-    const bool ok = e < p.region_px && (unsigned)iy < (unsigned)p.Hi && T.img0 + il < p.N;
-    d.slot = e < p.region_px ? il * p.IS + r * p.WS + ix + p.PL : -1;
-    d.goff = ok ? (((long)(T.img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci + seg_goff
+    const int iy = iy_lo + r;
+    const bool ok = e < p.region_px && (unsigned)iy < (unsigned)p.Hi && img0 + il < p.N;
+    d.slot = il * p.IS + r * p.WS + ix + p.PL;
+    d.goff = ok ? (((long)(img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci + seg_goff
                 : -1;
     return d;
   };
@@ -208,9 +206,8 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     }
     return v;
   };
-  // every slot of the region is written, rows outside the image with zeros: the previous tile's rows may sit there
   auto a_store = [&](const ADesc& d, u32x4 v) {
-    if (d.slot < 0) return;
+    if (d.goff < 0) return;  // outside the image / region: the slot keeps its zero fill
     if constexpr (SPLIT) {
       unsigned char* dst = A_lds + d.slot * 64 + (((cg >> 1) * 16) ^ swz(d.slot)) + (cg & 1) * 8;
       u32x2 pl[NPL];
@@ -222,16 +219,14 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     }
   };
   // whole-chunk staging with every load of a batch in flight before the first conversion
-  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
-  auto a_stage_sync = [&](int pass_begin, int c0, long seg, const Tile& T) {
-    const int ppx = opaque(pp);
+  auto a_stage_sync = [&](int pass_begin, int c0, long seg) {
     for (int j0 = pass_begin; j0 < p.npass; j0 += 4) {
       ADesc d[4];
       u32x4 v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        d[j].goff = -1; d[j].slot = -1;
-        if (j0 + j < p.npass) d[j] = a_desc(j0 + j, seg, T, ppx);
+        d[j].goff = -1; d[j].slot = 0;
+        if (j0 + j < p.npass) d[j] = a_desc(j0 + j, seg);
         v[j] = a_load(d[j], c0);
       }
 #pragma unroll
@@ -241,241 +236,220 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   // B: weight tile of one step = NPL x [64 co][32 ci]; thread -> (co row tid >> 2, 8-channel group tid & 3)
   const int brow = tid >> 2, bkg = tid & 3;
   const size_t w_plane = (size_t)p.ntw * p.Cop * p.Cip;
-  auto b_load = [&](int tw, int c0, int q, const Tile& T) {
-    return *reinterpret_cast<const u32x4*>(T.wp(p) + q * w_plane + ((size_t)tw * p.Cop + T.n0 + brow) * p.Cip + c0 + bkg * 8);
+  auto b_load = [&](int tw, int c0, int q) {
+    return *reinterpret_cast<const u32x4*>(wp_c + q * w_plane + ((size_t)tw * p.Cop + n0 + brow) * p.Cip + c0 + bkg * 8);
   };
   const int b_dst = brow * 64 + ((bkg * 16) ^ swz(brow));
   const int b_img = p.bdouble ? NPL * b_plane : 0;  // distance between the two weight-tile images
   auto b_store = [&](u32x4 v, int q, int img) {
     *reinterpret_cast<u32x4*>(B_lds + img * b_img + q * b_plane + b_dst) = v;
   };
-  float* red = reinterpret_cast<float*>(smem + a_buf + (p.bdouble ? 2 : 1) * NPL * b_plane);  // [4 waves][64 ch][2]
+
+  f32x4 acc[MF][4];
+#pragma unroll
+  for (int pf = 0; pf < MF; ++pf)
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) acc[pf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = p.Cip / KC, nsteps = nchunks * p.ntaps;
-  Tile cur = tile_ctx(lid);
   __syncthreads();  // zero fill complete
-  if (nsteps > 0) {  // (no taps: an output parity class of a strided data gradient that no filter tap reaches = zeros)
-    a_stage_sync(0, 0, p.seg_goff[0], cur);
+  if (nsteps > 0) {
+    a_stage_sync(0, 0, p.seg_goff[0]);
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q, cur), q, 0);
+    for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q, 0);
   }
   __syncthreads();
 
+  stamp(0);  // zero fill + synchronous staging of the first chunk / weight tile
   const unsigned char* Bb0 = B_lds + li * 64 + ((kg * 16) ^ swz(li));
+  // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
+  // (segment, chunk) pair changes
+  int g = 0, c = 0, t = 0;
+  long goff_cur = p.seg_goff[0];
   // The tap tables live in one register each (lane i holds entry i) and are read with v_readlane: a kernel-argument
   // load indexed by the step's tap has the latency of a cache access, shares its counter with the LDS reads, and sat
   // in front of every step's weight prefetch and fragment-read burst.
   static_assert(MAXTAPS <= 64, "one lane per tap");
   const int lane_toff = p.tap_off[lane < MAXTAPS ? lane : 0], lane_tw = p.tap_w[lane < MAXTAPS ? lane : 0];
+  int seg_lo = p.seg_begin[0], seg_hi = p.seg_begin[1];  // taps of segment g (kept in registers: a kernel-argument
+                                                         // load per step shows in the short steps of the bf16 kernels)
+  for (int ks = 0; ks < nsteps; ++ks) {
+    int tn = t + 1, cn = c, gn = g;
+    if (tn == seg_hi) {
+      tn = seg_lo; cn = c + 1;
+      if (cn == nchunks) { cn = 0; gn = g + 1; tn = seg_hi; }
+    }
+    const bool more = ks + 1 < nsteps;
+    const bool next_b = more && !(p.ablate & (1 | 8));  // bit 3 (timing only, wrong results): no weight staging and
+                                                       // no barriers inside a chunk = bound of a register-fed B path
+    const bool next_a = more && (cn != c || gn != g) && !(p.ablate & 1);  // this step ends (g, c): restage A after it
+    long goff_next = goff_cur;
+    if (gn != g && more) goff_next = p.seg_goff[gn];
+    const int toff = __builtin_amdgcn_readlane(lane_toff, t);
+    // 1. global loads: next step's weight tile; at a chunk's last tap also the next chunk of the input tile.
+    //    They complete under this step's MFMAs (and under the MFMAs of the workgroup sharing the CU).
+    u32x4 breg[NPL];
+    if (next_b) {
+      const int tw = __builtin_amdgcn_readlane(lane_tw, tn);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) breg[q] = b_load(tw, cn * KC, q);
+    }
+    u32x4 areg[MAXPF];
+    if (next_a) {
+#pragma unroll
+      for (int j = 0; j < MAXPF; ++j) {
+        areg[j] = u32x4{0, 0, 0, 0};
+        if (j < p.npass) areg[j] = a_load(a_desc(j, goff_next), cn * KC);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(1);  // address arithmetic + issue of the global loads
+    // 2. MFMAs of (chunk c, tap t)
+    if (!(p.ablate & 4)) {
+      bf16x8 wf[NPL][4];
+      const unsigned char* Bb = Bb0 + (ks & 1) * b_img;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) wf[q][cf] = *reinterpret_cast<const bf16x8*>(Bb + q * b_plane + cf * 1024);
+#pragma unroll
+      for (int pf = 0; pf < MF; ++pf) {
+        const int s = a_slot[pf] + toff;
+        const unsigned char* Ab = A_lds + s * 64 + ((kg * 16) ^ swz(s));
+        bf16x8 af[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) af[q] = *reinterpret_cast<const bf16x8*>(Ab + q * a_plane);
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          // (weight plane, activation plane) pairs, small terms first
+          if constexpr (NPL == 3) {
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[1], acc[pf][cf], 0, 0, 0);
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[2], acc[pf][cf], 0, 0, 0);
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][cf], af[0], acc[pf][cf], 0, 0, 0);
+          }
+          if constexpr (NPL >= 2) {
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[1], acc[pf][cf], 0, 0, 0);
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[0], acc[pf][cf], 0, 0, 0);
+          }
+          acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[0], acc[pf][cf], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(2);  // fragment reads + MFMA issue
+    if ((p.ablate & 8) && !next_a) { t = tn; c = cn; g = gn; goff_cur = goff_next; continue; }
+    // every wave has read this step's fragments — not needed for the weight tile alone when it goes to the other image
+    // (its last readers finished before the barrier that ended the previous step)
+    if (!p.bdouble || next_a) __syncthreads();
+    stamp(3);  // first barrier
+    // 3. commit the staged data
+    if (next_b && !(p.ablate & 2)) {
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) b_store(breg[q], q, (ks + 1) & 1);
+    }
+    if (next_a && !(p.ablate & 2)) {
+#pragma unroll
+      for (int j = 0; j < MAXPF; ++j)
+        if (j < p.npass) a_store(a_desc(j, goff_next), areg[j]);
+      a_stage_sync(MAXPF, cn * KC, goff_next);  // geometries with more than MAXPF passes: the rest without prefetch
+    }
+    if (next_a) stamp(5); else stamp(4);  // commit: wait for the loads, split, LDS stores (4: weight tile only)
+    __syncthreads();
+    stamp(6);  // second barrier
+    if (gn != g && more) { seg_lo = seg_hi; seg_hi = p.seg_begin[gn + 1]; }
+    t = tn; c = cn; g = gn; goff_cur = goff_next;
+  }
+
+  // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
   const bool vec_out = (p.Co % 4) == 0;
   const bool want_stats = SPLIT && p.stats != nullptr;  // block-uniform
-  unsigned gstep = 0;  // steps since the kernel began: the weight tile of step s sits in image s & 1
-
-  for (;;) {
-    const int lid_next = lid + wg_per_xcd;
-    const bool has_next = lid_next < tile_hi;
-    const Tile nxt = tile_ctx(has_next ? lid_next : lid);
-    // ---- this lane's input slots: fragment pf, column li (the output addresses are derived again in the epilogue:
-    // they would occupy registers through the whole K loop) ----------------------------------------------------
-    int a_slot[MF];
+  f32x4 st_s[4], st_q[4];
 #pragma unroll
-    for (int pf = 0; pf < MF; ++pf) {
-      const int m = (wave * MF + pf) * 16 + li;
-      const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
-      const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
-      const bool ok = il < p.TI && cur.sy0 + ry < p.Hs && cur.img0 + il < p.N;
-      a_slot[pf] = ok ? il * p.IS + ry * p.si * p.WS + sx * p.si + p.PL : p.PL;
-    }
-    f32x4 acc[MF][4];
+  for (int cf = 0; cf < 4; ++cf) { st_s[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; st_q[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int pf = 0; pf < MF; ++pf)
+  for (int pf = 0; pf < MF; ++pf) {
+    if (out_pix[pf] < 0) continue;
 #pragma unroll
-      for (int cf = 0; cf < 4; ++cf) acc[pf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
-    // (segment, chunk) pair changes
-    int g = 0, c = 0, t = 0;
-    long goff_cur = p.seg_goff[0];
-    int seg_lo = p.seg_begin[0], seg_hi = p.seg_begin[1];  // taps of segment g (kept in registers: a kernel-argument
-                                                           // load per step shows in the short steps of the bf16 kernels)
-    for (int ks = 0; ks < nsteps; ++ks, ++gstep) {
-      int tn = t + 1, cn = c, gn = g;
-      if (tn == seg_hi) {
-        tn = seg_lo; cn = c + 1;
-        if (cn == nchunks) { cn = 0; gn = g + 1; tn = seg_hi; }
+    for (int cf = 0; cf < 4; ++cf) {
+      const int co = n0 + cf * 16 + kg * 4;
+      if (co >= p.Co) continue;
+      f32x4 v = acc[pf][cf];
+      if (bias_c != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? bias_c[co + j] : 0.f;
       }
-      const bool last = ks + 1 == nsteps;  // the step after this one opens the next tile
-      if (last) { tn = 0; cn = 0; gn = 0; }
-      const bool more = !last || has_next;
-      Tile T = cur;  // (by value: a reference to one of two objects would put both in memory)
-      if (last) T = nxt;
-      const bool next_b = more && !(p.ablate & (1 | 8));  // bit 3 (timing only, wrong results): no weight staging and
-                                                         // no barriers inside a chunk = bound of a register-fed B path
-      const bool next_a = more && (last || cn != c || gn != g) && !(p.ablate & 1);  // restage A after this step
-      long goff_next = goff_cur;
-      if ((gn != g || last) && more) goff_next = p.seg_goff[gn];
-      const int toff = __builtin_amdgcn_readlane(lane_toff, t);
-      // 1. global loads: next step's weight tile; at a chunk's (tile's) last tap also the next chunk of the input
-      //    tile.  They complete under this step's MFMAs (and under the MFMAs of the workgroup sharing the CU).
-      u32x4 breg[NPL];
-      if (next_b) {
-        const int tw = __builtin_amdgcn_readlane(lane_tw, tn);
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) breg[q] = b_load(tw, cn * KC, q, T);
-      }
-      u32x4 areg[MAXPF];
-      if (next_a) {
-        const int ppx = opaque(pp);
-#pragma unroll
-        for (int j = 0; j < MAXPF; ++j) {
-          areg[j] = u32x4{0, 0, 0, 0};
-          if (j < p.npass) areg[j] = a_load(a_desc(j, goff_next, T, ppx), cn * KC);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // 2. MFMAs of (chunk c, tap t)
-      if (!(p.ablate & 4)) {
-        bf16x8 wf[NPL][4];
-        const unsigned char* Bb = Bb0 + (gstep & 1) * b_img;
-#pragma unroll
-        for (int q = 0; q < NPL; ++q)
-#pragma unroll
-          for (int cf = 0; cf < 4; ++cf) wf[q][cf] = *reinterpret_cast<const bf16x8*>(Bb + q * b_plane + cf * 1024);
-#pragma unroll
-        for (int pf = 0; pf < MF; ++pf) {
-          const int s = a_slot[pf] + toff;
-          const unsigned char* Ab = A_lds + s * 64 + ((kg * 16) ^ swz(s));
-          bf16x8 af[NPL];
-#pragma unroll
-          for (int q = 0; q < NPL; ++q) af[q] = *reinterpret_cast<const bf16x8*>(Ab + q * a_plane);
-#pragma unroll
-          for (int cf = 0; cf < 4; ++cf) {
-            // (weight plane, activation plane) pairs, small terms first
-            if constexpr (NPL == 3) {
-              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[1], acc[pf][cf], 0, 0, 0);
-              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[2], acc[pf][cf], 0, 0, 0);
-              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][cf], af[0], acc[pf][cf], 0, 0, 0);
-            }
-            if constexpr (NPL >= 2) {
-              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[1], acc[pf][cf], 0, 0, 0);
-              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[0], acc[pf][cf], 0, 0, 0);
-            }
-            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[0], acc[pf][cf], 0, 0, 0);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if ((p.ablate & 8) && !next_a) { t = tn; c = cn; g = gn; goff_cur = goff_next; continue; }
-      // every wave has read this step's fragments — not needed for the weight tile alone when it goes to the other
-      // image (its last readers finished before the barrier that ended the previous step)
-      if (!p.bdouble || next_a) __syncthreads();
-      // 3. commit the staged data
-      if (next_b && !(p.ablate & 2)) {
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) b_store(breg[q], q, (gstep + 1) & 1);
-      }
-      if (next_a && !(p.ablate & 2)) {
-        const int ppx = opaque(pp);
-#pragma unroll
-        for (int j = 0; j < MAXPF; ++j)
-          if (j < p.npass) a_store(a_desc(j, goff_next, T, ppx), areg[j]);
-        a_stage_sync(MAXPF, cn * KC, goff_next, T);  // more than MAXPF passes: the rest without prefetch
-      }
-      __syncthreads();
-      if (gn != g && !last) { seg_lo = seg_hi; seg_hi = p.seg_begin[gn + 1]; }
-      t = tn; c = cn; g = gn; goff_cur = goff_next;
-    }
-
-    // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -----------------------------
-    // (the stores are not waited for: they drain while the next tile's first steps run)
-    const int n0 = cur.n0;
-    const float* bias_c = p.bias ? p.bias + (size_t)cur.client * p.bias_client_stride : nullptr;
-    f32x4 st_s[4], st_q[4];
-#pragma unroll
-    for (int cf = 0; cf < 4; ++cf) { st_s[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; st_q[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int pf = 0; pf < MF; ++pf) {
-      const int m = (wave * MF + pf) * 16 + li;
-      const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
-      const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
-      if (!(il < p.TI && cur.sy0 + ry < p.Hs && cur.img0 + il < p.N)) continue;
-      const long out_pix = ((long)(cur.img0 + il) * p.Hout + (cur.sy0 + ry) * p.so + p.poy) * p.Wout + sx * p.so + p.pox;
-#pragma unroll
-      for (int cf = 0; cf < 4; ++cf) {
-        const int co = n0 + cf * 16 + kg * 4;
-        if (co >= p.Co) continue;
-        f32x4 v = acc[pf][cf];
-        if (bias_c != nullptr) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? bias_c[co + j] : 0.f;
-        }
-        if (want_stats) { st_s[cf] += v; st_q[cf] += v * v; }
-        if constexpr (SPLIT) {
-          float* dst = reinterpret_cast<float*>(p.out) + out_pix * p.Co + co;
-          if (vec_out) {
-            if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-            *reinterpret_cast<f32x4*>(dst) = v;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
-          }
+      if (want_stats) { st_s[cf] += v; st_q[cf] += v * v; }
+      if constexpr (SPLIT) {
+        float* dst = reinterpret_cast<float*>(p.out) + out_pix[pf] * p.Co + co;
+        if (vec_out) {
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = v;
         } else {
-          unsigned short* dst = reinterpret_cast<unsigned short*>(p.out) + out_pix * p.Co + co;
-          if (p.accumulate) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (co + j < p.Co) v[j] += __uint_as_float((unsigned)dst[j] << 16);
-          }
-          const u32x2 b = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
-          if (vec_out) *reinterpret_cast<u32x2*>(dst) = b;
-          else {
+          for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+        }
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(p.out) + out_pix[pf] * p.Co + co;
+        if (p.accumulate) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = (unsigned short)(b[j >> 1] >> ((j & 1) * 16));
-          }
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.Co) v[j] += __uint_as_float((unsigned)dst[j] << 16);
+        }
+        const u32x2 b = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+        if (vec_out) *reinterpret_cast<u32x2*>(dst) = b;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = (unsigned short)(b[j >> 1] >> ((j & 1) * 16));
         }
       }
     }
-    if constexpr (SPLIT) {
-      if (want_stats) {
-        // BatchNorm statistics of this tile: fixed-order tree over the 16 pixel lanes, then over the four waves
-        // through an LDS scratch of its own (the input image already holds the next tile's first chunk).  The
-        // scratch's previous readers are at least one K step, i.e. one barrier, behind.
+  }
+  if constexpr (SPLIT) {
+    if (want_stats) {
+      // BatchNorm statistics of this tile: fixed-order tree over the 16 pixel lanes, then over the four waves
+      // through LDS (every wave is past its last fragment read: the K loop ends with a barrier)
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            st_s[cf][j] += __shfl_xor(st_s[cf][j], o);
+            st_q[cf][j] += __shfl_xor(st_q[cf][j], o);
+          }
+      float* red = reinterpret_cast<float*>(smem);  // [4 waves][64 ch][2]
+      if (li == 0) {
 #pragma unroll
         for (int cf = 0; cf < 4; ++cf)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-              st_s[cf][j] += __shfl_xor(st_s[cf][j], o);
-              st_q[cf][j] += __shfl_xor(st_q[cf][j], o);
-            }
-        if (li == 0) {
-#pragma unroll
-          for (int cf = 0; cf < 4; ++cf)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int ch = cf * 16 + kg * 4 + j;
-              red[(wave * 64 + ch) * 2 + 0] = st_s[cf][j];
-              red[(wave * 64 + ch) * 2 + 1] = st_q[cf][j];
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-          const int ch = tid >> 1, which = tid & 1;
-          if (n0 + ch < p.Co) {
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) a += red[(w * 64 + ch) * 2 + which];
-            const int cl = cur.img0 / p.stats_B, in_cl = cur.img0 - cl * p.stats_B;
-            const int chunk = p.TI == 1 ? in_cl * p.tiles_per_img + (cur.mt - cur.img0 * p.tiles_per_img) : in_cl / p.TI;
-            p.stats[(((size_t)cl * p.stats_nchunk + chunk) * p.Co + n0 + ch) * 2 + which] = a;
+          for (int j = 0; j < 4; ++j) {
+            const int ch = cf * 16 + kg * 4 + j;
+            red[(wave * 64 + ch) * 2 + 0] = st_s[cf][j];
+            red[(wave * 64 + ch) * 2 + 1] = st_q[cf][j];
           }
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int ch = tid >> 1, which = tid & 1;
+        if (n0 + ch < p.Co) {
+          float a = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) a += red[(w * 64 + ch) * 2 + which];
+          const int cl = img0 / p.stats_B, in_cl = img0 - cl * p.stats_B;
+          const int chunk = p.TI == 1 ? in_cl * p.tiles_per_img + (mt - img0 * p.tiles_per_img) : in_cl / p.TI;
+          p.stats[(((size_t)cl * p.stats_nchunk + chunk) * p.Co + n0 + ch) * 2 + which] = a;
         }
       }
     }
-    if (!has_next) break;
-    lid = lid_next;
-    cur = nxt;
+  }
+  if constexpr (PROF) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(7);  // epilogue, stores acknowledged
+    if (lane == 0 && p.prof != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(p.prof + i, pf_t[i]);
+      atomicAdd(p.prof + 8, 1ull);
+    }
   }
 }
 
@@ -561,7 +535,7 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
       const int rows = q.TI > 1 ? (q.TI - 1) * (q.IR - share) + q.IR : q.IR;
       q.IS = q.TI > 1 ? (q.IR - share) * p.WS : q.IR * p.WS;
       q.NS = round_up(rows * p.WS + hpad + p.PL + 1, 4);
-      long lds = (long)npl * q.NS * 64 + 2L * npl * BN * 64 + RED_BYTES;
+      long lds = (long)npl * q.NS * 64 + 2L * npl * BN * 64;
       q.bdouble = 1;
       if (lds > LDS_TOTAL / wgs_per_cu(mf) || no_bdouble()) { lds -= (long)npl * BN * 64; q.bdouble = 0; }
       q.region_px = q.TI * q.IR * p.Wi;
@@ -589,9 +563,21 @@ int stats_chunks(const IgemmParams& p, int B) {
   return B * p.tiles_per_img;
 }
 
+// BLADES_IGEMM_PROF=1: device buffer of the phase-cycle sums (16 x u64), read and cleared by blades_conv_igemm_prof
+unsigned long long* prof_buffer() {
+  static unsigned long long* buf = [] {
+    const char* e = getenv("BLADES_IGEMM_PROF");
+    unsigned long long* b = nullptr;
+    if (e && atoi(e) == 1 && hipMalloc(&b, 16 * sizeof(unsigned long long)) == hipSuccess)
+      (void)hipMemset(b, 0, 16 * sizeof(unsigned long long));
+    return b;
+  }();
+  return buf;
+}
+
 template <int NPL, int MF, bool SPLIT>
 int launch(const IgemmParams& p, hipStream_t st) {
-  const size_t lds = (size_t)NPL * p.NS * 64 + (size_t)(p.bdouble ? 2 : 1) * NPL * BN * 64 + RED_BYTES;
+  const size_t lds = (size_t)NPL * p.NS * 64 + (size_t)(p.bdouble ? 2 : 1) * NPL * BN * 64;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<NPL, MF, SPLIT>),
@@ -599,18 +585,21 @@ int launch(const IgemmParams& p, hipStream_t st) {
     attr = true;
   }
   const int blocks = p.n_mtiles * p.n_ntiles;
-  // persistent tiles: at most the resident workgroups (BLADES_IGEMM_GRID: another cap — tests walk many tiles per
-  // workgroup on small problems with it; 0 = one workgroup per tile, the pre-persistent behaviour)
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n;
-  }();
-  const char* e = getenv("BLADES_IGEMM_GRID");
-  int cap = e ? atoi(e) : cus * wgs_per_cu(MF);
-  cap = cap <= 0 ? 0 : (cap + 7) / 8 * 8;
-  int grid = (blocks + 7) / 8 * 8;
-  if (cap > 0 && grid > cap) grid = cap;
+  const int grid = (blocks + 7) / 8 * 8;
+  if constexpr (NPL == 3 && MF >= 2 && SPLIT) {
+    if (prof_buffer() != nullptr) {
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<3, MF, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / wgs_per_cu(MF));
+        attr2 = true;
+      }
+      IgemmParams q = p;
+      q.prof = prof_buffer();
+      hipLaunchKernelGGL((conv_igemm_kernel<3, MF, true, true>), dim3(grid), dim3(256), lds, st, q);
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((conv_igemm_kernel<NPL, MF, SPLIT>), dim3(grid), dim3(256), lds, st, p);
   return 0;
 }
@@ -775,6 +764,16 @@ BLADES_API int blades_conv_igemm2(const void* in, const float* w, const float* b
       const int rc = dispatch(q, npl, ay, ax, st);
       if (rc != 0) return rc;
     }
+  return 0;
+}
+
+// diagnostics: copies the 16 phase-cycle sums of the PROF kernel to `host` and clears them; 1 = profiling is off
+BLADES_API int blades_conv_igemm_prof(unsigned long long* host) {
+  unsigned long long* b = prof_buffer();
+  if (b == nullptr) return 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 2;
+  if (hipMemcpy(host, b, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+  (void)hipMemset(b, 0, 16 * sizeof(unsigned long long));
   return 0;
 }
 

@@ -130,3 +130,17 @@ def test_allgather_layout_equals_alltoall(tmp_path, agg):
         # rank 0 sends (G-1)/G of its rows' columns in the all-to-all, receives all columns of everybody else's
         # training rows in the all-gather: roughly G times as much
         assert ag["comm_bytes"]["allgather"] > 1.2 * a2a["comm_bytes"]["alltoall"]
+
+
+@pytest.mark.parametrize("agg,adv", [({"type": "Clippedclustering"}, {"type": "blades.adversaries.ALIEAdversary"}),
+                                     ({"type": "Signguard"}, {"type": "blades.adversaries.IPMAdversary", "scale": 0.1}),
+                                     ({"type": "DnC", "sub_dim": 500}, {"type": "blades.adversaries.MinMaxAdversary"})],
+                         ids=["Clippedclustering", "Signguard", "DnC"])
+def test_allgather_layout_replicas_stay_equal(tmp_path, monkeypatch, agg, adv):
+    """Replicated aggregation: the ranks' copies of theta are compared every round here (BLADES_REPLICA_CHECK_EVERY=1;
+    a fork raises inside the run), for the aggregators with host clustering / sampled columns."""
+    monkeypatch.setenv("BLADES_REPLICA_CHECK_EVERY", "1")
+    spec = {"K": 9, "f": 2, "agg": agg, "adv": adv, "rounds": 3, "root": str(tmp_path), "smom": 0.9}
+    ref = run(1, spec, str(tmp_path / "w1.pt"))
+    ag = run(2, dict(spec, layout="allgather"), str(tmp_path / "g2.pt"))
+    torch.testing.assert_close(ag["theta"], ref["theta"], rtol=1e-3, atol=1e-4)

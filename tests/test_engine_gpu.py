@@ -227,3 +227,25 @@ def test_round_planes_and_gradient_join_are_bitwise_neutral(tmp_path, model):
                 os.environ[k] = v
     assert loss_new == loss_old
     assert torch.equal(U_new, U_old)
+
+
+def test_dropout_masks_do_not_depend_on_chunk_streams(tmp_path):
+    """with several local steps the chunks of a round sit at different step numbers on different HIP
+    streams at the same time; the dropout kernels read their (round, step) tag on the device when they execute.  Every
+    chunk owns its tag scalar (DropContext.bind), so one stream and three streams give the same update rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    old = os.environ.get("BLADES_CHUNK_STREAMS")
+    try:
+        os.environ["BLADES_CHUNK_STREAMS"] = "1"
+        U1, l1, e1 = _run(tmp_path, "0", "mnist", "mlp", "LabelFlipAdversary", rounds=3, K=8, f=2, chunk=2, nb=3, lr=0.1)
+        os.environ["BLADES_CHUNK_STREAMS"] = "3"
+        U3, l3, e3 = _run(tmp_path, "0", "mnist", "mlp", "LabelFlipAdversary", rounds=3, K=8, f=2, chunk=2, nb=3, lr=0.1)
+    finally:
+        if old is None:
+            os.environ.pop("BLADES_CHUNK_STREAMS", None)
+        else:
+            os.environ["BLADES_CHUNK_STREAMS"] = old
+    assert e1.n_streams == 1 and e3.n_streams == 3
+    assert l1 == l3
+    assert torch.equal(U1, U3)

@@ -402,18 +402,15 @@ def test_conv_igemm_kernel(dev, N, Ci, H, W, Co, k, s, p, npl):
     (24, 32, 32, 32, 64, 1, 1, 0, 4), (14, 20, 9, 9, 24, 5, 1, 2, 7),
 ])
 @pytest.mark.parametrize("npl", [3, 1])
-@pytest.mark.parametrize("grid", [8, 16])
-def test_conv_igemm_persistent_tiles(dev, monkeypatch, N, Ci, H, W, Co, k, s, p, B, npl, grid):
-    """A workgroup of conv_igemm walks several tiles (grid capped at 8 / 16 workgroups here; 512 on the bench): the next
-    tile's first input chunk / weight tile are staged behind the previous tile's last step, rows that were image
-    rows for one tile are padding for the next, the BatchNorm partial sums use their own LDS scratch.  Forward (with
-    statistics), data gradient and its accumulate mode against fp64."""
+def test_conv_igemm_stats_planes_accumulate(dev, N, Ci, H, W, Co, k, s, p, B, npl):
+    """Many-tile launches of conv_igemm against fp64: forward with the BatchNorm partial sums from the epilogue, data
+    gradient, ready-made weight planes (one split per round, bitwise equal to the per-call split) and the data
+    gradient's accumulate mode (the other gradient branch of a residual block added in the epilogue)."""
     import torch.nn.functional as F
     from blades_amd import ops
 
     h = ops._h()
-    monkeypatch.setenv("BLADES_IGEMM_GRID", str(grid))
-    g = torch.Generator().manual_seed(N * 1000 + Ci + grid)
+    g = torch.Generator().manual_seed(N * 1000 + Ci)
     dt = torch.bfloat16 if npl == 1 else torch.float32
     x = torch.randn(N, Ci, H, W, generator=g).to(dt)
     w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
@@ -457,17 +454,14 @@ def test_conv_igemm_persistent_tiles(dev, monkeypatch, N, Ci, H, W, Co, k, s, p,
     (3, 4, 64, 32, 32, 64, 3, 1, 1), (5, 3, 64, 16, 16, 128, 3, 2, 1), (4, 6, 128, 8, 8, 128, 3, 1, 1),
     (3, 8, 256, 4, 4, 256, 3, 1, 1), (7, 5, 64, 8, 8, 128, 1, 2, 0), (2, 12, 32, 4, 4, 64, 3, 1, 1),
 ])
-@pytest.mark.parametrize("grid", [0, 8])
-def test_conv_igemm_per_client_weights(dev, monkeypatch, Kc, B, Ci, H, W, Co, k, s, p, grid):
+def test_conv_igemm_per_client_weights(dev, Kc, B, Ci, H, W, Co, k, s, p):
     """Per-client weight sets (local steps > 1): image n uses client n // B's weights and bias, taken as rows of a
     wider strided matrix like the engine's W.  Forward and data gradient against a per-client fp64 convolution
-    (B not a power of two, 4x4 / 8x8 maps, stride 2, several tiles per workgroup)."""
+    (B not a power of two, 4x4 / 8x8 maps, stride 2)."""
     import torch.nn.functional as F
     from blades_amd import ops
 
     h = ops._h()
-    if grid:
-        monkeypatch.setenv("BLADES_IGEMM_GRID", str(grid))
     g = torch.Generator().manual_seed(Kc * 100 + Ci)
     nw = Co * Ci * k * k
     Wm = torch.randn(Kc, 11 + nw + Co + 5, generator=g) / (Ci * k * k) ** 0.5  # rows of a wider matrix
