@@ -37,16 +37,8 @@ class AdaptiveAdversary(Adversary):
         mask = algorithm.benign_mask
         mean = ops.col_mean(U, mask)
         mn, mx = ops.col_min_max(U, mask)
-        b = 2.0
-        u = ops.philox_uniform(U.shape[1], _seed(self.global_config), 3000 + self._round, ctx.col_offset,
-                               device=U.device)
-        s = torch.sign(mean)
-        out = torch.zeros_like(mean)
-        out = torch.where((s == -1) & (mx > 0), mx * (1 + u * (b - 1)), out)
-        out = torch.where((s == -1) & (mx < 0), mx * (1 + u * (1 / b - 1)), out)
-        out = torch.where((s == 1) & (mn > 0), mn * (1 / b + u * (1 - 1 / b)), out)
-        out = torch.where((s == 1) & (mn < 0), mn * (b + u * (1 - b)), out)
-        out = torch.where(s == 0, mean, out)
+        # one fused kernel: Philox uniform per global coordinate + the five sign / extremum cases
+        out = ops.adaptive_forge(mean, mn, mx, _seed(self.global_config), 3000 + self._round, ctx.col_offset, 2.0)
         ops.set_rows_(U, algorithm.malicious_rows, out)
         return out
 
@@ -105,27 +97,45 @@ class MinMaxAdversary(Adversary):
 
 
 class SignGuardAdversary(Adversary):
-    """Noise with the benign mean's sign statistics (``signguard_adversary.py:39-67``):
-    a fraction pos/D of the coordinates gets ``+U(0,1)``, neg/D gets ``-U(0,1)``,
-    the rest 0, at random positions.
+    """Noise with the benign mean's sign statistics (``signguard_adversary.py:39-67``): exactly ``pos`` coordinates
+    get ``+U(0,1)``, exactly ``neg`` get ``-U(0,1)``, the rest 0, at uniformly random positions.
 
-    The reference builds the three blocks with exact counts and applies a CPU
-    ``randperm(D)``; here each coordinate draws its class independently with
-    those probabilities (counter-based RNG on the global coordinate index), which
-    matches the counts to O(sqrt(D)) and is shard-invariant."""
+    The reference concatenates the three blocks and applies a CPU ``randperm(D)``.  Here every coordinate gets a
+    unique random sort key (31 Philox bits : global index); the ``pos`` smallest keys are the positive positions, the
+    next ``neg`` the negative ones — the same distribution with the same exact counts, as a device sort plus two
+    one-pass kernels, and invariant to how D is sharded over ranks (the two thresholds are found by a bisection on
+    the key value with one scalar all-reduce per step when the matrix is column-sharded)."""
 
     def forge(self, algorithm, U, ctx):
         mean = ops.col_mean(U, algorithm.benign_mask)
-        valid = torch.arange(U.shape[1], device=U.device) < ctx.d_valid
-        cnt = torch.stack([((mean > 0) & valid).sum(), ((mean < 0) & valid).sum()]).double()
+        _, cnt = ops.row_stats(mean.unsqueeze(0), ctx.d_valid if ctx.distributed else None)  # [1, 3]: > 0, < 0, == 0
+        cnt = cnt[0, :2].to(torch.int64)
         if ctx.distributed:
-            ctx.all_reduce(cnt)
-        p_pos, p_neg = cnt[0] / ctx.d_total, cnt[1] / ctx.d_total
+            c = cnt.double()
+            ctx.all_reduce(c)
+            cnt = c.round().to(torch.int64)
+        ranks = torch.stack([cnt[0], cnt[0] + cnt[1]])  # keys of global rank pos / pos + neg bound the two classes
         seed = _seed(self.global_config)
-        cls = ops.philox_uniform(U.shape[1], seed, 4000 + 2 * self._round, ctx.col_offset, device=U.device)
-        mag = ops.philox_uniform(U.shape[1], seed, 4001 + 2 * self._round, ctx.col_offset, device=U.device)
-        out = torch.where(cls < p_pos, mag, torch.where(cls < p_pos + p_neg, -mag, torch.zeros_like(mag)))
-        out = torch.where(valid, out, torch.zeros_like(out))
+        n = U.shape[1]
+        keys = ops.perm_keys(n, seed, 4000 + 2 * self._round, ctx.col_offset, ctx.col_offset + ctx.d_valid
+                             if ctx.distributed else n, device=U.device)
+        srt = torch.sort(keys).values
+        big = torch.full((1,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=U.device)
+        if not ctx.distributed:
+            thr = torch.cat([srt, big]).index_select(0, ranks.clamp(max=n))
+        else:
+            # largest t with #(keys < t) <= rank, over all shards: bisection over the 63 key bits
+            lo = torch.zeros(2, dtype=torch.int64, device=U.device)
+            hi = big.expand(2).clone()
+            for _ in range(63):
+                mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1)  # upper middle, no int64 overflow
+                c = torch.searchsorted(srt, mid).double()  # keys < mid on this shard
+                ctx.all_reduce(c)
+                ok = c.round().to(torch.int64) <= ranks
+                lo = torch.where(ok, mid, lo)
+                hi = torch.where(ok, hi, mid - 1)
+            thr = lo
+        out = ops.signguard_forge(keys, thr, seed, 4001 + 2 * self._round, ctx.col_offset)
         ops.set_rows_(U, algorithm.malicious_rows, out)
         return out
 

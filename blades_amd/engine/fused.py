@@ -69,6 +69,22 @@ class GradSink:
         off, n = self.offsets[id(param)]
         return self.block[:, off: off + n]
 
+    def write_bias(self, param, g3: torch.Tensor):
+        """``g3``: [Kc, R, C] gradient of a layer's output -> ``scale[c] * sum_r g3[c, r]`` into the bias columns of
+        row c.  On the GPU one kernel reduces and writes the update rows (ops/csrc/elementwise.hip) instead of a
+        library reduction plus a scaled copy."""
+        if g3.is_cuda and g3.dtype in (torch.float32, torch.bfloat16) and self.block is not None:
+            from blades_amd import ops
+
+            h = ops._h()
+            if hasattr(h, "bias_grad_"):
+                off, n = self.offsets[id(param)]
+                acc = id(param) in self._written
+                h.bias_grad_(g3.reshape(-1, g3.shape[-1]), self.Kc, self.block, off, self.scale, acc)
+                self._written.add(id(param))
+                return
+        self.write(param, g3.sum(dim=1, dtype=torch.float32))
+
     def write(self, param, g: torch.Tensor):
         """``g``: [Kc, *param.shape] (any float dtype) -> scaled fp32 row slices."""
         v = self.view(param)
@@ -230,8 +246,7 @@ class _PCConvFn(torch.autograd.Function):
                 raise RuntimeError("stem weight gradient: the 1x1 kernel rejected the im2col problem")
             sink._written.add(id(mod.weight))
             if mod.bias is not None:
-                g = gy.permute(0, 2, 3, 1)
-                sink.write(mod.bias, g.reshape(Kc, -1, gy.shape[1]).sum(dim=1, dtype=torch.float32))
+                sink.write_bias(mod.bias, gy.permute(0, 2, 3, 1).reshape(Kc, -1, gy.shape[1]))
             return None, None, None, None
         join = ctx.join
         if ctx.needs_input_grad[0] and ctx.own:
@@ -271,7 +286,7 @@ class _PCConvFn(torch.autograd.Function):
         if mod.bias is not None:
             # per-client bias gradient: fp32 accumulation straight from the (NHWC) bf16 tensor, no fp32 copy
             g = gy.permute(0, 2, 3, 1) if gy.dim() == 4 else gy.unsqueeze(1)
-            sink.write(mod.bias, g.reshape(Kc, -1, gy.shape[1]).sum(dim=1, dtype=torch.float32))
+            sink.write_bias(mod.bias, g.reshape(Kc, -1, gy.shape[1]))
         return dx, None, None, None
 
 
@@ -324,6 +339,18 @@ class PCConv2d(nn.Module):
         h = _hipmod()
         ks = self.weight.shape[2:]
         if not h.conv_wgrad_supported(x, gy, ks, self.stride, self.padding, self.dilation):
+            if (tuple(self.dilation) == (1, 1) and x.dim() == 4 and x.dtype == gy.dtype
+                    and x.dtype in (torch.float32, torch.bfloat16) and hasattr(h, "conv_wgrad_im2col_")
+                    and _os.environ.get("BLADES_WGRAD_IM2COL", "1") != "0"):
+                # no tile schedule for this geometry (4x4 / stride 4 patch embedding, 5x5 / 7x7 tokenizers, ...):
+                # dW_c = gy_c^T im2col(x_c) on the grouped-GEMM kernel instead of MIOpen's grouped weight gradient
+                sink = self.sink
+                off, _ = sink.offsets[id(self.weight)]
+                acc = id(self.weight) in sink._written
+                h.conv_wgrad_im2col_(x, gy, Kc, sink.block, off, sink.scale, acc, ks, self.stride, self.padding,
+                                     sink.npl)
+                sink._written.add(id(self.weight))
+                return True
             return False
         x = x.contiguous(memory_format=torch.channels_last)
         sink = self.sink
@@ -365,10 +392,30 @@ class PCConv2d(nn.Module):
         return dw.reshape(Kc, Co, Ci, self.weight.shape[2], self.weight.shape[3])
 
 
+_LINEAR_IMPL = _os.environ.get("BLADES_LINEAR_IMPL", "hip").lower()  # "lib": hipBLASLt / bmm, for A/B runs
+
+
+def _own_linear(x, mod) -> bool:
+    """Does the framework's own MFMA kernel run this Linear layer?  (ops/_hip.py linear_forward: conv_igemm on the
+    [M, K, 1, 1] view — fp32 tensors as exact bf16 planes, shared or per-client weights.)"""
+    if not (x.is_cuda and _LINEAR_IMPL == "hip"):
+        return False
+    npl = mod.sink.npl
+    if x.dtype != (torch.bfloat16 if npl == 1 else torch.float32):
+        return False
+    return _hipmod().linear_supported(x, mod.weight, npl)
+
+
 class _PCLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mod):
         ctx.mod = mod
+        ctx.own = _own_linear(x, mod)
+        if ctx.own:
+            # y = x W^T + b on the matrix cores, fp32 grade; with per-client weights row m uses client m // R's set
+            w = mod.sink.param(weight).detach()
+            ctx.save_for_backward(x, w)
+            return _hipmod().linear_forward(x, w, mod.sink.param(mod.bias), mod.sink.npl, planes=mod.planes("fwd"))
         if mod.sink.W is not None:
             # per-client weights: one strided-batched library GEMM over the clients
             Kc = mod.sink.Kc
@@ -388,10 +435,14 @@ class _PCLinearFn(torch.autograd.Function):
         mod = ctx.mod
         sink: GradSink = mod.sink
         Kc = sink.Kc
-        if w.dim() == 3:
-            dx = torch.bmm(gy.reshape(Kc, -1, gy.shape[-1]), w).reshape(x.shape) if ctx.needs_input_grad[0] else None
-        else:
-            dx = gy @ w if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.own:
+                dx = _hipmod().linear_dgrad(gy.to(x.dtype), w, sink.npl, planes=mod.planes("dgrad")).reshape(x.shape)
+            elif w.dim() == 3:
+                dx = torch.bmm(gy.reshape(Kc, -1, gy.shape[-1]), w).reshape(x.shape)
+            else:
+                dx = gy @ w
         g3 = gy.reshape(Kc, -1, gy.shape[-1])  # [Kc, B*, out]
         x3 = x.reshape(Kc, -1, x.shape[-1])  # [Kc, B*, in]
         if x.is_cuda and x.dtype == gy.dtype and x.dtype in (torch.float32, torch.bfloat16) \
@@ -405,7 +456,7 @@ class _PCLinearFn(torch.autograd.Function):
         else:
             sink.write(mod.weight, torch.bmm(g3.transpose(1, 2), x3))
         if mod.bias is not None:
-            sink.write(mod.bias, g3.sum(dim=1, dtype=torch.float32))
+            sink.write_bias(mod.bias, g3)
         return dx, None, None
 
 
@@ -413,9 +464,25 @@ class PCLinear(nn.Module):
     def __init__(self, lin: nn.Linear, sink: GradSink):
         super().__init__()
         self.weight, self.bias, self.sink = lin.weight, lin.bias, sink
+        self._planes = {}
 
     def forward(self, x):
         return _PCLinearFn.apply(x, self.weight, self)
+
+    def prepare_planes(self):
+        """Operand planes of the shared weight for this round's forward / data-gradient launches (see PCConv2d)."""
+        w = self.weight.detach()
+        if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and _LINEAR_IMPL == "hip"):
+            return
+        h, npl, pl = _hipmod(), self.sink.npl, self._planes
+        w4 = w.contiguous().view(w.shape[0], w.shape[1], 1, 1)
+        pl["fwd"] = h.conv_planes(w4, 0, npl, out=pl.get("fwd"))
+        pl["dgrad"] = h.conv_planes(w4, 1, npl, out=pl.get("dgrad"))
+
+    def planes(self, kind: str):
+        if not self.sink.planes_valid or self.sink.W is not None:
+            return None
+        return self._planes.get(kind)
 
 
 def _bn_forward_ref(x, res, gamma, beta, Kc, eps, relu):
@@ -534,14 +601,17 @@ class _PCLayerNormFn(torch.autograd.Function):
     def forward(ctx, x, mod):
         if len(mod.normalized_shape) != 1:
             raise NotImplementedError("PCLayerNorm normalises the last dimension only")
-        if mod.sink.W is not None:
-            raise NotImplementedError("per-client LayerNorm weights are not implemented (grouped / vmap path)")
         ctx.hip = x.is_cuda and _hipmod().ln_supported(x)
         if ctx.hip:  # one-wave-per-row kernel (ops/csrc/layernorm.hip); backward recomputes xhat from x
-            y, mean, rstd = _hipmod().ln_forward(x, mod.weight, mod.bias, mod.eps)
+            # (per-client weights, local steps > 1: gamma / beta are [Kc, C] views into the clients' weight rows)
+            gamma = mod.sink.param(mod.weight)
+            y, mean, rstd = _hipmod().ln_forward(x, gamma, mod.sink.param(mod.bias), mod.eps)
             ctx.mod = mod
+            ctx.gamma = gamma.detach() if gamma is not None else None
             ctx.save_for_backward(x, mean, rstd)
             return y
+        if mod.sink.W is not None:
+            raise NotImplementedError("per-client LayerNorm weights need the hand-written kernel (GPU)")
         xf = x.float()
         var, mean = torch.var_mean(xf, dim=-1, unbiased=False, keepdim=True)
         rstd = torch.rsqrt(var + mod.eps)
@@ -571,7 +641,7 @@ class _PCLayerNormFn(torch.autograd.Function):
             if mod.bias is not None:
                 offb = sink.offsets[id(mod.bias)][0]
                 sink._written.add(id(mod.bias))
-            dx = _hipmod().ln_backward(x, gy.to(x.dtype), mod.weight, mean, rstd, Kc, sink.scale, sink.block, offg,
+            dx = _hipmod().ln_backward(x, gy.to(x.dtype), ctx.gamma, mean, rstd, Kc, sink.scale, sink.block, offg,
                                        offb, acc)
             return dx, None
         xhat, rstd = ctx.saved_tensors
@@ -666,6 +736,14 @@ class _PCBroadcastFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, proxy, n, dtype):
         ctx.proxy = proxy
+        sink: GradSink = proxy.sink
+        if sink.W is not None:
+            # per-client weights (local steps > 1): sample row c*B + b gets client c's copy of the embedding
+            pc = sink.param(p).detach().to(dtype)  # [Kc, 1, ...]
+            Kc = pc.shape[0]
+            if n % Kc:
+                raise NotImplementedError("broadcast parameter: batch is not a multiple of the number of clients")
+            return pc.expand(Kc, n // Kc, *p.shape[1:]).reshape(n, *p.shape[1:])
         return p.to(dtype).expand(n, *p.shape[1:])
 
     @staticmethod
@@ -695,6 +773,78 @@ class PCParam:
     def expand(self, *sizes):
         sizes = sizes[0] if len(sizes) == 1 and isinstance(sizes[0], (tuple, list)) else sizes
         return self._bcast(sizes[0], self.param.dtype)
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    """Channels-last max-pool on ops/csrc/elementwise.hip, the preceding ReLU folded in (relu o maxpool = maxpool o
+    relu); the forward pass leaves one byte per output element (window position of the maximum), the backward pass
+    gathers — no ATen ``max_pool2d_with_indices`` / clamp kernels in the CNN and CCT rounds."""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p, relu):
+        y, idx = _hipmod().maxpool_forward(x, k, s, p, relu)
+        ctx.save_for_backward(idx)
+        ctx.geom = (tuple(x.shape), k, s, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        shape, k, s, p = ctx.geom
+        return _hipmod().maxpool_backward(gy, idx, shape, k, s, p), None, None, None, None
+
+
+class PCMaxPool2d(nn.Module):
+    def __init__(self, pool: nn.MaxPool2d, relu: bool):
+        super().__init__()
+        self.k, self.s, self.p = pool.kernel_size, pool.stride, pool.padding
+        self.dilation, self.ceil_mode, self.relu = pool.dilation, pool.ceil_mode, relu
+
+    def extra_repr(self):
+        return f"kernel_size={self.k}, stride={self.s}, padding={self.p}, relu_folded={self.relu}"
+
+    def forward(self, x):
+        if x.is_cuda and x.dim() == 4 and _hipmod().maxpool_supported(x, self.k, self.s, self.p, self.dilation,
+                                                                      self.ceil_mode):
+            return _MaxPoolFn.apply(x, self.k, self.s, self.p, self.relu)
+        if self.relu:
+            x = F.relu(x)
+        return F.max_pool2d(x, self.k, self.s, self.p, self.dilation, self.ceil_mode)
+
+
+class PCActivation(nn.Module):
+    """nn.ReLU / nn.GELU leaves of a template: the dispatching functions of ops/activations.py."""
+
+    def __init__(self, kind: str):
+        super().__init__()
+        self.kind = kind
+
+    def extra_repr(self):
+        return self.kind
+
+    def forward(self, x):
+        from blades_amd.ops import activations as A
+
+        return A.relu(x) if self.kind == "relu" else A.gelu(x)
+
+
+class _GlobalAvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (int(x.shape[2]), int(x.shape[3]))
+        return _hipmod().avgpool_global_forward(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _hipmod().avgpool_global_backward(gy, ctx.hw)
+
+
+def global_avg_pool(x: torch.Tensor, k: int) -> torch.Tensor:
+    """``F.avg_pool2d(x, k)`` flattened to [N, C] when the window is the whole map (the ResNet head)."""
+    if x.is_cuda and x.dim() == 4 and x.shape[2] == x.shape[3] == k and x.dtype in (torch.float32, torch.bfloat16):
+        return _GlobalAvgPoolFn.apply(x)
+    out = F.avg_pool2d(x, k)
+    return out.reshape(out.size(0), -1)
 
 
 class PCBatchNorm2d(nn.Module):
@@ -760,8 +910,7 @@ class PCResNet(nn.Module):
         n = self.net
         out = _conv_bn(n.conv1, n.bn1, x, relu=True)
         out = n.layer4(n.layer3(n.layer2(n.layer1(out))))
-        out = F.avg_pool2d(out, 4)
-        return n.linear(out.reshape(out.size(0), -1))
+        return n.linear(global_avg_pool(out, 4))
 
 
 # ---------------------------------------------------------------------------
@@ -814,6 +963,13 @@ def build_template(model: nn.Module, sink: GradSink) -> nn.Module:
     tmpl = copy.deepcopy(model, memo)
 
     def swap(mod):
+        if isinstance(mod, nn.Sequential):
+            # ReLU directly in front of a max-pool: folded into the pooling kernel (FashionCNN, the CCT tokenizers)
+            kids = list(mod.named_children())
+            for (n0, c0), (n1, c1) in zip(kids, kids[1:]):
+                if type(c0) is nn.ReLU and isinstance(c1, nn.MaxPool2d):
+                    setattr(mod, n0, nn.Identity())
+                    setattr(mod, n1, PCMaxPool2d(c1, relu=True))
         for name, child in list(mod.named_children()):
             if isinstance(child, nn.Conv2d):
                 setattr(mod, name, PCConv2d(child, sink))
@@ -823,6 +979,12 @@ def build_template(model: nn.Module, sink: GradSink) -> nn.Module:
                 setattr(mod, name, PCBatchNorm2d(child, sink))
             elif isinstance(child, nn.LayerNorm):
                 setattr(mod, name, PCLayerNorm(child, sink))
+            elif isinstance(child, nn.MaxPool2d):
+                setattr(mod, name, PCMaxPool2d(child, relu=False))
+            elif type(child) is nn.ReLU:
+                setattr(mod, name, PCActivation("relu"))
+            elif type(child) is nn.GELU and getattr(child, "approximate", "none") == "none":
+                setattr(mod, name, PCActivation("gelu"))
             elif isinstance(child, _cct_attention()):
                 swap(child)  # its Linear layers first
                 setattr(mod, name, PCAttention(child, sink))
@@ -864,6 +1026,10 @@ class FusedFedSGD:
         self.amp_dtype = amp_dtype
         self.device = device
         self.sink.npl = 1 if amp_dtype == torch.bfloat16 else (2 if conv_planes == 2 else 3)
+        from blades_amd.tasks.mnist import MNIST
+
+        self._stock_loss = (getattr(type(task), "loss", None) is MNIST.loss
+                            and _os.environ.get("BLADES_FUSED_CE", "1") != "0")
 
     def begin_round(self):
         """The shared weights stay as they are until ``end_round()``: split every convolution's weight into its
@@ -871,7 +1037,7 @@ class FusedFedSGD:
         if self.device.type != "cuda" or _os.environ.get("BLADES_ROUND_PLANES", "1") == "0":
             return
         for m in self.template.modules():
-            if isinstance(m, PCConv2d):
+            if isinstance(m, (PCConv2d, PCLinear)):
                 m.prepare_planes()
         self.sink.planes_valid = True
 
@@ -889,8 +1055,22 @@ class FusedFedSGD:
         if x.dim() == 4 and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
         self.template.train()
-        # the input needs no gradient: first-layer backward skips its dgrad
-        logits = self.template(x)
+        from blades_amd.ops.activations import fused_scope
+
+        with fused_scope():
+            # the input needs no gradient: first-layer backward skips its dgrad
+            logits = self.template(x)
+            return self._loss_backward(logits, Y, Kc, B)
+
+    def _loss_backward(self, logits, Y, Kc, B):
+        """Per-client losses [Kc] and the backward pass of their sum.  The stock task loss (clamped mean
+        cross-entropy, reference fllib/tasks/mnist.py:8-18) and its gradient come from one kernel
+        (ops/csrc/elementwise.hip ce_clamp); a task with its own ``loss`` goes through autograd under ``vmap``."""
+        if logits.is_cuda and self._stock_loss and logits.dim() == 2:
+            lg = logits.detach().float().reshape(Kc, B, -1)
+            losses, dz = _hipmod().ce_clamp(lg, Y, 0.0, 1e6)
+            logits.backward(dz.reshape(logits.shape).to(logits.dtype))
+            return losses
         lg = logits.float().reshape(Kc, B, -1)
         losses = torch.vmap(lambda z, y: self.task.loss(_identity, z, y))(lg, Y)
         losses.sum().backward()
@@ -913,15 +1093,15 @@ class FusedFedSGD:
             if x.dim() == 4 and x.is_cuda:
                 x = x.contiguous(memory_format=torch.channels_last)
             self.template.train()
-            with torch.enable_grad():
+            from blades_amd.ops.activations import fused_scope
+
+            with torch.enable_grad(), fused_scope():
                 logits = self.template(x)
-                lg = logits.float().reshape(Kc, B, -1)
-                losses = torch.vmap(lambda z, y: self.task.loss(_identity, z, y))(lg, Y)
-                losses.sum().backward()
+                losses = self._loss_backward(logits, Y, Kc, B)
             missing = [k for k in self.sink.offsets if k not in self.sink._written]
             if missing:
                 raise NotImplementedError(f"{len(missing)} parameters received no per-client gradient")
-            return losses.detach()
+            return losses
         finally:
             self.sink.W = None
 
@@ -938,7 +1118,10 @@ class FusedFedSGD:
         if x.dim() == 4 and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
         self.template.eval()
-        out = self.template(x).float().reshape(Kc, m, -1)
+        from blades_amd.ops.activations import fused_scope
+
+        with fused_scope():
+            out = self.template(x).float().reshape(Kc, m, -1)
         self.template.train()
         return out
 

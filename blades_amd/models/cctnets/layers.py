@@ -13,6 +13,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from blades_amd.ops.activations import gelu
+
 
 class DropPath(nn.Module):
     """Stochastic depth: drops the whole residual branch per sample."""
@@ -61,7 +63,7 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src):
         src = src + self.drop_path(self.self_attn(self.pre_norm(src)))
         src = self.norm1(src)
-        src2 = self.linear2(self.dropout1(F.gelu(self.linear1(src))))
+        src2 = self.linear2(self.dropout1(gelu(self.linear1(src))))
         return src + self.drop_path(self.dropout2(src2))
 
 

@@ -11,6 +11,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from blades_amd.ops.activations import gelu
+
 from .layers import DropPath, sinusoidal_embedding
 
 
@@ -106,7 +108,7 @@ class MaskedTransformerEncoderLayer(nn.Module):
     def forward(self, src, mask=None, *args, **kwargs):
         src = src + self.drop_path(self.self_attn(self.pre_norm(src), mask))
         src = self.norm1(src)
-        src2 = self.linear2(self.dropout1(F.gelu(self.linear1(src))))
+        src2 = self.linear2(self.dropout1(gelu(self.linear1(src))))
         return src + self.drop_path(self.dropout2(src2))
 
 

@@ -3,8 +3,9 @@
 Parameter names/order match ``fllib/models/mnist/mlp.py`` (fc1, fc2, fc3) so
 flattened update vectors line up with the reference's.
 """
-import torch.nn.functional as F
 from torch import nn
+
+from blades_amd.ops.activations import relu
 
 
 class MLP(nn.Module):
@@ -18,6 +19,6 @@ class MLP(nn.Module):
 
     def forward(self, x):
         x = x.reshape(x.shape[0], -1)  # one row per sample (also lets a grouped executor fold clients into the row)
-        x = self.dropout(F.relu(self.fc1(x)))
-        x = self.dropout(F.relu(self.fc2(x)))
+        x = self.dropout(relu(self.fc1(x)))
+        x = self.dropout(relu(self.fc2(x)))
         return self.fc3(x)

@@ -173,6 +173,25 @@ def philox_normal(n, seed, stream, offset=0, mean=0.0, std=1.0, device="cpu"):
     return ref.philox_normal(n, seed, stream, offset, mean, std, device)
 
 
+def adaptive_forge(mean, mn, mx, seed, stream, offset=0, b=2.0):
+    """Adaptive (Fang) attack vector in one pass (GPU: csrc/rng.hip adaptive_forge_kernel)."""
+    if mean.is_cuda and not _FORCE_REFERENCE:
+        return _h().adaptive_forge(mean.contiguous(), mn.contiguous(), mx.contiguous(), int(seed), int(stream), int(offset), b)
+    return ref.adaptive_forge(mean, mn, mx, seed, stream, offset, b)
+
+
+def perm_keys(n, seed, stream, offset, d_valid_end, device="cpu"):
+    if torch.device(device).type == "cuda" and not _FORCE_REFERENCE:
+        return _h().perm_keys(int(n), int(seed), int(stream), int(offset), int(d_valid_end), device)
+    return ref.perm_keys(n, seed, stream, offset, d_valid_end, device)
+
+
+def signguard_forge(keys, thresholds, seed, stream, offset=0):
+    if keys.is_cuda and not _FORCE_REFERENCE:
+        return _h().signguard_forge(keys.contiguous(), thresholds.contiguous(), int(seed), int(stream), int(offset))
+    return ref.signguard_forge(keys, thresholds, seed, stream, offset)
+
+
 def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite):
     if _use_hip(_f32c(U)):
         return _h().add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, overwrite)

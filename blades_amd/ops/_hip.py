@@ -36,6 +36,11 @@ def _sig(name, argtypes, restype=None):
     return fn
 
 
+def _opt_sig(name, argtypes, restype=None):
+    """A symbol newer than the oldest library ``BLADES_HIP_LIB`` may point at (same-box A/B runs): None if absent."""
+    return _sig(name, argtypes, restype) if hasattr(_lib, name) else None
+
+
 _weighted_col_sum = _sig("blades_weighted_col_sum", [_P, c_long, c_int, c_long, _P, _P, _P])
 _col_stats = _sig("blades_col_stats", [_P, c_long, c_int, c_long, _P, _P, _P, _P, _P, c_int, c_float, c_float, _P, _P,
                                        c_int, _P, _P])
@@ -355,6 +360,38 @@ def philox_uniform(n, seed, stream, offset, device):
 def philox_normal(n, seed, stream, offset, mean, std, device):
     out = _empty(n, device=device, dtype=torch.float32)
     _philox_normal(_ptr(out), n, seed & (2 ** 64 - 1), stream & 0xFFFFFFFF, offset, mean, std, _stream())
+    return out
+
+
+_adaptive_forge = _opt_sig("blades_adaptive_forge", [_P, _P, _P, _P, c_long, c_ulonglong, c_uint, c_ulonglong, c_float, _P])
+_perm_keys = _opt_sig("blades_perm_keys", [_P, c_long, c_ulonglong, c_uint, c_ulonglong, c_ulonglong, _P])
+_signguard_forge = _opt_sig("blades_signguard_forge", [_P, _P, _P, c_long, c_ulonglong, c_uint, c_ulonglong, _P])
+
+
+def adaptive_forge(mean, mn, mx, seed, stream, offset, b=2.0):
+    n = mean.numel()
+    for t in (mean, mn, mx):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+            raise ValueError("adaptive_forge: need contiguous fp32 CUDA vectors of equal length")
+    out = _empty(n, device=mean.device, dtype=torch.float32)
+    _adaptive_forge(_ptr(mean), _ptr(mn), _ptr(mx), _ptr(out), n, seed & (2 ** 64 - 1), stream & 0xFFFFFFFF, offset,
+                    float(b), _stream())
+    return out
+
+
+def perm_keys(n, seed, stream, offset, d_valid_end, device):
+    out = _empty(n, device=device, dtype=torch.int64)
+    _perm_keys(_ptr(out), n, seed & (2 ** 64 - 1), stream & 0xFFFFFFFF, offset, int(d_valid_end), _stream())
+    return out
+
+
+def signguard_forge(keys, thresholds, seed, stream, offset):
+    if not (keys.is_cuda and keys.dtype == torch.int64 and keys.is_contiguous() and thresholds.is_cuda
+            and thresholds.dtype == torch.int64 and thresholds.numel() == 2 and thresholds.is_contiguous()):
+        raise ValueError("signguard_forge: keys int64 [n], thresholds int64 [2], both contiguous CUDA tensors")
+    out = _empty(keys.numel(), device=keys.device, dtype=torch.float32)
+    _signguard_forge(_ptr(keys), _ptr(thresholds), _ptr(out), keys.numel(), seed & (2 ** 64 - 1), stream & 0xFFFFFFFF,
+                     offset, _stream())
     return out
 
 
@@ -763,19 +800,48 @@ def ln_supported(x: torch.Tensor) -> bool:
     return x.is_cuda and x.dtype in _ACT_DTYPES and x.dim() >= 2 and x.shape[-1] <= 1024 and x.numel() > 0
 
 
+_ln_fwd2 = _opt_sig("blades_ln_forward2", [_P, _P, _P, c_long, c_int, c_float, _P, _P, _P, c_int, c_long, c_long, c_int,
+                                           _P], c_int)
+_ln_bwd2 = _opt_sig("blades_ln_backward2", [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_long, c_long, c_long, c_int,
+                                            _P, _P, c_int, c_long, _P], c_int)
+
+
+def _ln_affine(t, C: int, device, name: str):
+    """[C] shared by all rows (stride 0), or [Kc, C] — one vector per client, any client stride (rows of the engine's
+    per-client weight matrix are used in place)."""
+    if t is None:
+        return None, 0, 0
+    t = t.detach()
+    if t.dim() == 2:
+        if t.shape[1] != C or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+            t = t.to(device=device, dtype=torch.float32).contiguous()
+        return t, int(t.stride(0)) if t.shape[0] > 1 else C, int(t.shape[0])
+    return _vec(t, C, device, name=name), 0, 0
+
+
 def ln_forward(x, gamma, beta, eps: float):
-    """LayerNorm over the last dimension.  Returns (y, mean [rows], rstd [rows])."""
+    """LayerNorm over the last dimension.  ``gamma`` / ``beta``: ``[C]``, or ``[Kc, C]`` per client (rows of ``x`` are
+    client-major).  Returns (y, mean [rows], rstd [rows])."""
     if not ln_supported(x):
         raise ValueError(f"ln_forward: unsupported input {x.dtype} {tuple(x.shape)}")
     x = x.contiguous()
     C = x.shape[-1]
     rows = x.numel() // C
-    gamma = _vec(gamma.detach(), C, x.device, name="gamma") if gamma is not None else None
-    beta = _vec(beta.detach(), C, x.device, name="beta") if beta is not None else None
+    gamma, gs, gk = _ln_affine(gamma, C, x.device, "gamma")
+    beta, bs, bk = _ln_affine(beta, C, x.device, "beta")
+    Kc = max(gk, bk)
+    if Kc and (rows % Kc or (gk and bk and gk != bk)):
+        raise ValueError("ln_forward: per-client affine vectors do not match the rows")
     y = _empty_like(x)
     stats = _empty(2, rows, device=x.device, dtype=torch.float32)
-    rc = _ln_fwd(_ptr(x), _ptr(gamma), _ptr(beta), rows, C, eps, _ptr(y), _ptr(stats[0]), _ptr(stats[1]),
-                 x.element_size(), _stream())
+    if Kc and _ln_fwd2 is None:
+        raise RuntimeError("ln_forward: this library build has no per-client affine mode")
+    if _ln_fwd2 is not None:
+        rc = _ln_fwd2(_ptr(x), _ptr(gamma), _ptr(beta), rows, C, eps, _ptr(y), _ptr(stats[0]), _ptr(stats[1]),
+                      x.element_size(), gs, bs, rows // Kc if Kc else 1, _stream())
+    else:
+        rc = _ln_fwd(_ptr(x), _ptr(gamma), _ptr(beta), rows, C, eps, _ptr(y), _ptr(stats[0]), _ptr(stats[1]),
+                     x.element_size(), _stream())
     if rc != 0:
         raise ValueError("ln_forward: unsupported shape")
     return y, stats[0], stats[1]
@@ -783,7 +849,7 @@ def ln_forward(x, gamma, beta, eps: float):
 
 def ln_backward(x, gy, gamma, mean, rstd, Kc: int, coef, U_block, off_gamma: int, off_beta: int, accumulate: bool):
     """dx of LayerNorm; coef[c] * (dgamma_c, dbeta_c) go to U_block[c, off_gamma / off_beta : + C] (an offset < 0
-    skips that gradient).  Rows of ``x`` are client-major: rows / Kc per client."""
+    skips that gradient).  Rows of ``x`` are client-major: rows / Kc per client.  ``gamma``: [C] or [Kc, C]."""
     if not (ln_supported(x) and gy.dtype == x.dtype and gy.shape == x.shape):
         raise ValueError("ln_backward: gy must match x")
     x, gy = x.contiguous(), gy.contiguous()
@@ -792,7 +858,9 @@ def ln_backward(x, gy, gamma, mean, rstd, Kc: int, coef, U_block, off_gamma: int
     if rows % Kc or mean.numel() != rows or rstd.numel() != rows:
         raise ValueError("ln_backward: row count does not match")
     R = rows // Kc
-    gamma = _vec(gamma.detach(), C, x.device, name="gamma") if gamma is not None else None
+    gamma, gs, gk = _ln_affine(gamma, C, x.device, "gamma")
+    if gk and gk != Kc:
+        raise ValueError("ln_backward: per-client gamma does not match the number of clients")
     ld = 0
     if U_block is not None:
         K, Dl, ld = _chk_matrix(U_block)
@@ -801,8 +869,14 @@ def ln_backward(x, gy, gamma, mean, rstd, Kc: int, coef, U_block, off_gamma: int
         coef = _vec(coef, Kc, x.device, name="coef")
     partial = _empty(Kc * _ln_nchunk(R) * C * 2, device=x.device, dtype=torch.float32)
     dx = _empty_like(x)
-    rc = _ln_bwd(_ptr(x), _ptr(gy), _ptr(gamma), _ptr(mean), _ptr(rstd), Kc, R, C, _ptr(coef), _ptr(U_block), ld,
-                 off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(dx), x.element_size(), _stream())
+    if gk and _ln_bwd2 is None:
+        raise RuntimeError("ln_backward: this library build has no per-client affine mode")
+    if _ln_bwd2 is not None:
+        rc = _ln_bwd2(_ptr(x), _ptr(gy), _ptr(gamma), _ptr(mean), _ptr(rstd), Kc, R, C, _ptr(coef), _ptr(U_block), ld,
+                      off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(dx), x.element_size(), gs, _stream())
+    else:
+        rc = _ln_bwd(_ptr(x), _ptr(gy), _ptr(gamma), _ptr(mean), _ptr(rstd), Kc, R, C, _ptr(coef), _ptr(U_block), ld,
+                     off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(dx), x.element_size(), _stream())
     if rc != 0:
         raise ValueError("ln_backward: unsupported shape")
     return dx
@@ -928,11 +1002,6 @@ def conv_igemm_supported(x: torch.Tensor, weight: torch.Tensor, stride, pad, dil
             and x.shape[3] + 2 * pad[1] >= kw and x.shape[3] <= 256)
 
 
-def _opt_sig(name, argtypes, restype=None):
-    """A symbol newer than the oldest library ``BLADES_HIP_LIB`` may point at (same-box A/B runs): None if absent."""
-    return _sig(name, argtypes, restype) if hasattr(_lib, name) else None
-
-
 _conv_igemm2 = _opt_sig("blades_conv_igemm2", [_P, _P, _P, _P, _P] + [c_int] * 14 + [c_long, c_long, _P, c_int, c_int, _P],
                         c_int)
 _conv_wprep = _opt_sig("blades_conv_wprep", [_P, _P] + [c_int] * 7 + [c_long, _P], c_int)
@@ -1027,6 +1096,54 @@ def stem_im2col(x: torch.Tensor, k: int, pad: int) -> torch.Tensor:
     return out
 
 
+_im2col_c = _opt_sig("blades_im2col", [_P, _P, c_long] + [c_int] * 13 + [_P], c_int)
+
+
+def im2col(x: torch.Tensor, kh: int, kw: int, sh: int, sw: int, ph: int, pw: int) -> torch.Tensor:
+    """Channels-last ``[N, Ci, H, W]`` (fp32 / bf16) -> ``[N*Ho*Wo, Ci*kh*kw]`` with column ``ci*kh*kw + r*kw + s`` =
+    the input under tap (r, s) of channel ci (zero outside the image): the row order of ``weight.reshape(Co, -1)``."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in _ACT_DTYPES):
+        raise ValueError(f"im2col: expected a CUDA fp32/bf16 4-D tensor, got {x.dtype} {tuple(x.shape)}")
+    x = x.contiguous(memory_format=torch.channels_last)
+    N, Ci, H, W = x.shape
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    if Ho < 1 or Wo < 1:
+        raise ValueError("im2col: empty output")
+    K = Ci * kh * kw
+    col = _empty((N * Ho * Wo, K), dtype=x.dtype, device=x.device)
+    rc = _im2col_c(_ptr(x), _ptr(col), N, H, W, Ci, Ho, Wo, kh, kw, sh, sw, ph, pw, K, x.element_size(), _stream())
+    if rc != 0:
+        raise ValueError(f"im2col: rejected (rc={rc})")
+    return col
+
+
+def conv_wgrad_im2col_(x, gy, Kc: int, U_block, off: int, coef, accumulate: bool, ks, stride, pad, npl: int = 3):
+    """Per-client convolution weight gradient for geometries conv_wgrad.hip has no schedule for (kernel sizes other
+    than 1 / 3, strides other than 1 / 2, rectangular kernels): ``dW_c = gy_c^T im2col(x_c)`` on the grouped-GEMM
+    kernel, written (scaled by coef[c]) into ``U_block[c, off : off + Co*Ci*kh*kw]``.  Images are processed in
+    slabs so that the im2col tensor stays under ~1 GiB."""
+    kh, kw = int(ks[0]), int(ks[1])
+    sh, sw = int(stride[0]), int(stride[1])
+    ph, pw = int(pad[0]), int(pad[1])
+    N, Ci, H, W = x.shape
+    Co = gy.shape[1]
+    if N % Kc:
+        raise ValueError("conv_wgrad_im2col_: batch is not a multiple of the number of clients")
+    B = N // Kc
+    Ho, Wo = gy.shape[2], gy.shape[3]
+    gy = gy.contiguous(memory_format=torch.channels_last)
+    g2 = gy.permute(0, 2, 3, 1).reshape(N * Ho * Wo, Co)
+    K = Ci * kh * kw
+    per_client = B * Ho * Wo * K * x.element_size()
+    cps = max(1, min(Kc, (1 << 30) // max(per_client, 1)))  # clients per slab
+    for c0 in range(0, Kc, cps):
+        c1 = min(Kc, c0 + cps)
+        col = im2col(x[c0 * B: c1 * B], kh, kw, sh, sw, ph, pw)
+        linear_wgrad_(col, g2[c0 * B * Ho * Wo: c1 * B * Ho * Wo], c1 - c0, U_block[c0:c1], off, coef[c0:c1], accumulate,
+                      npl)
+    return True
+
+
 def conv_forward(x, weight, bias, stride: int, pad: int, npl: int, stats_B: int = 0, planes=None):
     """y = conv2d(x, weight, bias) for channels-last x; fp32 (npl 3 / 2) or bf16 (npl 1) in and out.
     ``stats_B`` > 0 (fp32 tensors, ``stats_B`` images per client): returns ``(y, pre_stats)`` where ``pre_stats`` is
@@ -1070,6 +1187,211 @@ def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int, planes=None, 
     _conv_call(gy, weight, None, dx, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 1, npl, planes=planes,
                accumulate=accumulate_into is not None)
     return dx
+
+
+# ---------------------------------------------------------------------------
+# Linear forward / data gradient on the same kernel: Y = X W^T (+ bias) is the 1x1 convolution of the [M, K, 1, 1]
+# "image" X with the [N, K, 1, 1] filter W (reference: nn.Linear in fllib/models/mnist/mlp.py,
+# fllib/models/fashionmnist/cnn.py, the CCT blocks).  Shared weights [N, K] or one set per client [Kc, N, K] (rows of
+# client c = rows c*R .. (c+1)*R - 1 of X), fp32 tensors as exact bf16 planes or bf16 tensors.
+def linear_supported(x: torch.Tensor, weight: torch.Tensor, npl: int) -> bool:
+    want = torch.bfloat16 if npl == 1 else torch.float32
+    return (x.is_cuda and x.dtype == want and x.dim() >= 2 and x.numel() > 0 and weight.dtype == torch.float32
+            and weight.dim() in (2, 3) and weight.shape[-1] == x.shape[-1])
+
+
+def _as_rows(t: torch.Tensor) -> torch.Tensor:
+    t2 = t.reshape(-1, t.shape[-1])
+    if not t2.is_contiguous() or t2.data_ptr() % 16:
+        t2 = t2.contiguous()
+        if t2.data_ptr() % 16:
+            t2 = t2.clone()
+    return t2
+
+
+def _w4(weight: torch.Tensor):
+    """[N, K] -> [N, K, 1, 1]; [Kc, N, K] (any client stride, contiguous inside a client) -> [Kc, N, K, 1, 1]."""
+    w = weight.detach()
+    if w.dim() == 2:
+        return w.contiguous().view(w.shape[0], w.shape[1], 1, 1)
+    Kc, N, K = w.shape
+    if w.stride(2) != 1 or w.stride(1) != K:
+        w = w.contiguous()
+    return w.as_strided((Kc, N, K, 1, 1), (w.stride(0), K, 1, 1, 1))
+
+
+def linear_forward(x, weight, bias, npl: int, planes=None):
+    """``x [..., K] @ weight^T (+ bias)`` -> ``[..., N]`` in x's dtype."""
+    if not linear_supported(x, weight, npl):
+        raise ValueError(f"linear_forward: unsupported operands {x.dtype} {tuple(x.shape)} / {tuple(weight.shape)}")
+    x2 = _as_rows(x)
+    M, K = x2.shape
+    N = int(weight.shape[-2])
+    if weight.dim() == 3 and M % int(weight.shape[0]):
+        raise ValueError("linear_forward: rows are not a multiple of the number of clients")
+    y = _empty((M, N), dtype=x.dtype, device=x.device)
+    xv = x2.as_strided((M, K, 1, 1), (K, 1, K, K))
+    yv = y.as_strided((M, N, 1, 1), (N, 1, N, N))
+    _conv_call(xv, _w4(weight), bias, yv, M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, npl, planes=planes)
+    return y.reshape(*x.shape[:-1], N)
+
+
+def linear_dgrad(gy, weight, npl: int, planes=None):
+    """``gy [..., N] @ weight`` -> ``[..., K]``."""
+    if not (gy.is_cuda and gy.dim() >= 2 and weight.dim() in (2, 3) and weight.shape[-2] == gy.shape[-1]
+            and gy.dtype == (torch.bfloat16 if npl == 1 else torch.float32) and weight.dtype == torch.float32):
+        raise ValueError(f"linear_dgrad: unsupported operands {gy.dtype} {tuple(gy.shape)} / {tuple(weight.shape)}")
+    g2 = _as_rows(gy)
+    M, N = g2.shape
+    K = int(weight.shape[-1])
+    if weight.dim() == 3 and M % int(weight.shape[0]):
+        raise ValueError("linear_dgrad: rows are not a multiple of the number of clients")
+    dx = _empty((M, K), dtype=gy.dtype, device=gy.device)
+    gv = g2.as_strided((M, N, 1, 1), (N, 1, N, N))
+    dv = dx.as_strided((M, K, 1, 1), (K, 1, K, K))
+    _conv_call(gv, _w4(weight), None, dv, M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 1, npl, planes=planes)
+    return dx.reshape(*gy.shape[:-1], K)
+
+
+# ---------------------------------------------------------------------------
+# streaming kernels of the fused executor (ops/csrc/elementwise.hip)
+_bias_grad_nchunk = _opt_sig("blades_bias_grad_nchunk", [c_int, c_int], c_int)
+_bias_grad = _opt_sig("blades_bias_grad", [_P, c_int, c_int, c_int, _P, _P, c_long, c_long, c_int, _P, c_int, _P], c_int)
+_maxpool_fwd = _opt_sig("blades_maxpool_forward", [_P, _P, _P, c_long] + [c_int] * 13 + [_P], c_int)
+_maxpool_bwd = _opt_sig("blades_maxpool_backward", [_P, _P, _P, c_long] + [c_int] * 12 + [_P], c_int)
+_avgpool_fwd = _opt_sig("blades_avgpool_forward", [_P, _P, c_long, c_int, c_int, c_int, _P], c_int)
+_avgpool_bwd = _opt_sig("blades_avgpool_backward", [_P, _P, c_long, c_int, c_int, c_int, _P], c_int)
+_act_fwd = _opt_sig("blades_act_forward", [_P, _P, c_long, c_int, c_int, _P], c_int)
+_act_bwd = _opt_sig("blades_act_backward", [_P, _P, _P, c_long, c_int, c_int, _P], c_int)
+_ce_clamp = _opt_sig("blades_ce_clamp", [_P, c_long, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P], c_int)
+
+
+def bias_grad_(g, Kc: int, U_block, off: int, coef, accumulate: bool):
+    """U_block[c, off : off + C] (+)= coef[c] * sum over client c's rows of ``g`` ([Kc*R, C], fp32 or bf16)."""
+    if not (g.is_cuda and g.dim() == 2 and g.dtype in _ACT_DTYPES and g.shape[0] % Kc == 0):
+        raise ValueError(f"bias_grad_: expected a CUDA fp32/bf16 [Kc*R, C] tensor, got {g.dtype} {tuple(g.shape)}")
+    if not g.is_contiguous():
+        g = g.contiguous()
+    R, C = g.shape[0] // Kc, g.shape[1]
+    K, Dl, ld = _chk_matrix(U_block)
+    if K != Kc or off < 0 or off + C > Dl:
+        raise ValueError("bias_grad_: update-matrix block does not match")
+    coef = _vec(coef, Kc, g.device, name="coef")
+    partial = _empty(Kc * _bias_grad_nchunk(R, C) * C, device=g.device)
+    rc = _bias_grad(_ptr(g), Kc, R, C, _ptr(coef), _ptr(U_block), ld, off, int(accumulate), _ptr(partial),
+                    g.element_size(), _stream())
+    if rc != 0:
+        raise ValueError(f"bias_grad_: rejected (rc={rc})")
+    return True
+
+
+def _pool_geom(x, k, s, p):
+    kh, kw = (k, k) if isinstance(k, int) else (int(k[0]), int(k[1]))
+    s = k if s is None else s
+    sh, sw = (s, s) if isinstance(s, int) else (int(s[0]), int(s[1]))
+    ph, pw = (p, p) if isinstance(p, int) else (int(p[0]), int(p[1]))
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    return kh, kw, sh, sw, ph, pw, Ho, Wo
+
+
+def maxpool_supported(x, k, s, p, dilation=1, ceil_mode=False) -> bool:
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in _ACT_DTYPES and x.numel() > 0):
+        return False
+    if dilation not in (1, (1, 1)) or ceil_mode:
+        return False
+    kh, kw, sh, sw, ph, pw, Ho, Wo = _pool_geom(x, k, s, p)
+    return kh * kw <= 254 and Ho >= 1 and Wo >= 1 and 2 * ph <= kh and 2 * pw <= kw
+
+
+def maxpool_forward(x, k, s, p, relu: bool):
+    """Channels-last max-pool (ReLU of the input folded in when ``relu``).  Returns (y, idx) — idx feeds
+    ``maxpool_backward``."""
+    x = x.contiguous(memory_format=torch.channels_last)
+    kh, kw, sh, sw, ph, pw, Ho, Wo = _pool_geom(x, k, s, p)
+    N, C, H, W = x.shape
+    y = _empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    idx = _empty(N * Ho * Wo * C, dtype=torch.uint8, device=x.device)
+    rc = _maxpool_fwd(_ptr(x), _ptr(y), _ptr(idx), N, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw, int(relu),
+                      x.element_size(), _stream())
+    if rc != 0:
+        raise ValueError(f"maxpool_forward: rejected (rc={rc})")
+    return y, idx
+
+
+def maxpool_backward(gy, idx, in_shape, k, s, p):
+    N, C, H, W = in_shape
+    gy = gy.contiguous(memory_format=torch.channels_last)
+    x_like = torch.empty(0, dtype=gy.dtype, device=gy.device).new_empty((N, C, H, W))
+    kh, kw, sh, sw, ph, pw, Ho, Wo = _pool_geom(x_like, k, s, p)
+    if tuple(gy.shape) != (N, C, Ho, Wo) or idx.numel() != gy.numel():
+        raise ValueError("maxpool_backward: gy / idx do not match the pooling geometry")
+    dx = _empty((N, C, H, W), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
+    rc = _maxpool_bwd(_ptr(gy), _ptr(idx), _ptr(dx), N, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw, gy.element_size(),
+                      _stream())
+    if rc != 0:
+        raise ValueError(f"maxpool_backward: rejected (rc={rc})")
+    return dx
+
+
+def avgpool_global_forward(x):
+    """[N, C, H, W] channels-last -> [N, C] mean over the map."""
+    x = x.contiguous(memory_format=torch.channels_last)
+    N, C, H, W = x.shape
+    y = _empty((N, C), dtype=x.dtype, device=x.device)
+    if _avgpool_fwd(_ptr(x), _ptr(y), N, H * W, C, x.element_size(), _stream()) != 0:
+        raise ValueError("avgpool_global_forward: rejected")
+    return y
+
+
+def avgpool_global_backward(gy, hw):
+    gy = gy.contiguous()
+    N, C = gy.shape
+    H, W = hw
+    dx = _empty((N, C, H, W), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
+    if _avgpool_bwd(_ptr(gy), _ptr(dx), N, H * W, C, gy.element_size(), _stream()) != 0:
+        raise ValueError("avgpool_global_backward: rejected")
+    return dx
+
+
+def act_forward(x, mode: int):
+    """mode 0: GELU (erf), 1: ReLU."""
+    x = x if x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)) else x.contiguous()
+    y = _empty_like(x)
+    if _act_fwd(_ptr(x), _ptr(y), x.numel(), mode, x.element_size(), _stream()) != 0:
+        raise ValueError("act_forward: rejected")
+    return y
+
+
+def act_backward(saved, gy, mode: int):
+    if gy.stride() != saved.stride() or gy.dtype != saved.dtype:
+        gy = gy.to(saved.dtype).contiguous()
+        if gy.stride() != saved.stride():
+            saved = saved.contiguous()
+    dx = _empty_like(saved)
+    if _act_bwd(_ptr(saved), _ptr(gy), _ptr(dx), saved.numel(), mode, saved.element_size(), _stream()) != 0:
+        raise ValueError("act_backward: rejected")
+    return dx
+
+
+def ce_clamp(logits, labels, lo: float, hi: float, want_grad: bool = True):
+    """Per-client clamped mean cross-entropy (reference fllib/tasks/mnist.py:8-18) of ``logits [Kc, B, C]`` (fp32) and
+    ``labels [Kc, B]``: returns (loss [Kc], d(sum_c loss_c)/dlogits [Kc, B, C] or None).  Labels must lie in [0, C)
+    (checked by the callers that create them; out-of-range entries are read as class 0)."""
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 3):
+        raise ValueError("ce_clamp: logits must be a CUDA fp32 [Kc, B, C] tensor")
+    lg = logits if logits.is_contiguous() else logits.contiguous()
+    Kc, B, C = lg.shape
+    y = labels.reshape(Kc, B)
+    if y.dtype != torch.int64:
+        y = y.long()
+    y = y.contiguous()
+    loss = _empty(Kc, device=lg.device)
+    dz = _empty((Kc, B, C), device=lg.device) if want_grad else None
+    rc = _ce_clamp(_ptr(lg), C, _ptr(y), Kc, B, C, float(lo), float(hi), c_void_p(0), _ptr(loss), _ptr(dz), _stream())
+    if rc != 0:
+        raise ValueError(f"ce_clamp: rejected (rc={rc})")
+    return loss, dz
 
 
 # ---------------------------------------------------------------------------

@@ -541,7 +541,13 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
       q.region_px = q.TI * q.IR * p.Wi;
       const bool fits = lds <= LDS_TOTAL / wgs_per_cu(mf) && q.region_px < (1 << 20) && p.Wi < 4096 && q.IR * p.Wi < 4096 * 64;
       if (fits) {
-        const double cost = (double)q.n_mtiles * BM * (mf == 4 ? 1.0 : mf == 2 ? 1.12 : 1.35);
+        // cost = rounds of resident workgroups x tile size x per-MFMA overhead of the smaller tiles.  A launch that
+        // does not fill the chip once (the Linear layers of the small models, run as 1x1 convolutions over [M, K, 1, 1])
+        // takes as long as one tile: smaller tiles then win.
+        const long tiles = (long)q.n_mtiles * (p.Cop / BN);
+        const long slots = 256L * wgs_per_cu(mf);
+        const double rounds = tiles > slots ? (double)tiles / slots : 1.0;
+        const double cost = rounds * BM * (mf == 4 ? 1.0 : mf == 2 ? 1.12 : 1.35);
         if (best_mf == 0 || cost < best_cost) { best_mf = mf; best_cost = cost; best = q; }
         break;
       }

@@ -18,6 +18,7 @@
 // consecutive floats 8t+4h..8t+4h+3 with one b128 and feeds them to 4 MFMAs), which
 // a dot product does not care about.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -126,6 +127,130 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict_
       }
 }
 
+// ---- the same product on the bf16 matrix cores, fp32 grade (round 3) ---------------------------------------------
+// Every fp32 element is split exactly into three bf16 planes (x = h + m + l) on its way into LDS and a tile product
+// is the six plane pairs hh + hm + mh + hl + lh + mm with fp32 accumulation — the scheme of conv_igemm.hip (dropped
+// terms <= 2^-26 |a||b|).  The fp32 MFMA runs at 1/16 of the bf16 rate, so six bf16 products are still 2.7x cheaper.
+// Identical rows still cancel exactly in g_ii + g_jj - 2 g_ij: the three entries are produced by the same
+// instruction sequence on the same bits (same K-steps, same split-K ranges, same slab order), whichever tile they
+// sit in, and a_h*b_l / a_l*b_h are the same numbers when a = b.
+//   tile 128 x 128, 4 waves as 2 x 2, wave = 4 x 4 fragments of v_mfma_f32_16x16x32_bf16, K-step = 32 columns;
+//   LDS image per operand [3 planes][128 rows][32 k] bf16 with 64-byte rows, 16-byte groups XOR-swizzled by row bit 2
+//   (conflict-free ds_read_b128 fragment reads, see conv_igemm.hip); global loads run one K-step ahead in registers.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256, 2) void gram_planes_kernel(const float* __restrict__ U, long ld, int K, long Dl,
+                                                             long cols_per_split, int ntile, int Kp,
+                                                             float* __restrict__ slabs) {
+  constexpr int B = 128, PLANE = B * 64;  // bytes of one plane image
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * PLANE];
+  unsigned char* As = lds;
+  unsigned char* Bs = lds + 3 * PLANE;
+  int pair = blockIdx.x, ti = 0;
+  while (pair >= ntile - ti) { pair -= ntile - ti; ++ti; }
+  const int tj = ti + pair;
+  const long c_begin = (long)blockIdx.y * cols_per_split;
+  long c_end = c_begin + cols_per_split;
+  if (c_end > Dl) c_end = Dl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, kg = lane >> 4;
+  const bool al = (ld & 3) == 0;
+  auto swz = [](int row) { return (row & 4) << 3; };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int LOADS = B * (BK / 4) / 256;  // float4 per thread per operand = 4
+  f32x4 ra[LOADS], rb[LOADS];
+  auto fetch = [&](long c0) {
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int f = q * 256 + tid;
+      const int row = f >> 3, k4 = (f & 7) * 4;
+      const long col = c0 + k4;
+      const int ga = ti * B + row, gb = tj * B + row;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      if (col + 4 <= c_end && al) {
+        if (ga < K) va = *reinterpret_cast<const f32x4*>(U + (long)ga * ld + col);
+        if (gb < K) vb = *reinterpret_cast<const f32x4*>(U + (long)gb * ld + col);
+      } else {
+        for (int j = 0; j < 4; ++j) {
+          if (col + j < c_end) {
+            if (ga < K) va[j] = U[(long)ga * ld + col + j];
+            if (gb < K) vb[j] = U[(long)gb * ld + col + j];
+          }
+        }
+      }
+      ra[q] = va; rb[q] = vb;
+    }
+  };
+  auto commit = [&](unsigned char* img, f32x4 r, int row, int k4) {
+    unsigned char* dst = img + row * 64 + ((((k4 >> 3)) * 16) ^ swz(row)) + ((k4 >> 2) & 1) * 8;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const bf16x4 b = __builtin_convertvector(r, bf16x4);
+      *reinterpret_cast<u32x2*>(dst + q * PLANE) = __builtin_bit_cast(u32x2, b);
+      if (q < 2) r -= __builtin_convertvector(b, f32x4);
+    }
+  };
+  if (c_begin < c_end) fetch(c_begin);
+  for (long c0 = c_begin; c0 < c_end; c0 += BK) {
+    __syncthreads();  // previous step's fragment reads done
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int f = q * 256 + tid;
+      commit(As, ra[q], f >> 3, (f & 7) * 4);
+      commit(Bs, rb[q], f >> 3, (f & 7) * 4);
+    }
+    __syncthreads();
+    if (c0 + BK < c_end) fetch(c0 + BK);
+    bf16x8 bf[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int row = wc * 64 + b * 16 + li;
+      const unsigned char* src = Bs + row * 64 + ((kg * 16) ^ swz(row));
+#pragma unroll
+      for (int q = 0; q < 3; ++q) bf[q][b] = *reinterpret_cast<const bf16x8*>(src + q * PLANE);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = wr * 64 + a * 16 + li;
+      const unsigned char* src = As + row * 64 + ((kg * 16) ^ swz(row));
+      bf16x8 af[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) af[q] = *reinterpret_cast<const bf16x8*>(src + q * PLANE);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        // small terms first; (a plane, b plane)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1][b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2][b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0][b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1][b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0][b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0][b], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+  // C/D map of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+  float* slab = slabs + (long)blockIdx.y * Kp * Kp;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = ti * B + wr * 64 + a * 16 + kg * 4 + q;
+        const int col = tj * B + wc * 64 + b * 16 + li;
+        slab[(long)row * Kp + col] = acc[a][b][q];
+      }
+}
+
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nsplit, int Kp, int K,
                                                           int B, float* __restrict__ out) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -163,9 +288,13 @@ BLADES_API void blades_gram(const float* U, long ld, int K, long Dl, float* slab
   blades_gram_plan(K, Dl, &B, &nt, &nsplit, &cps);
   const int Kp = nt * B, pairs = nt * (nt + 1) / 2;
   if (Dl <= 0) { hipMemsetAsync(out, 0, sizeof(float) * K * K, st); return; }
+  // BLADES_GRAM_IMPL=f32: the exact-fp32 MFMA kernel for every size (A/B runs); default: bf16 planes for 128-row tiles
+  static const bool f32_only = [] { const char* e = getenv("BLADES_GRAM_IMPL"); return e && e[0] == 'f'; }();
   if (B == 64)
     hipLaunchKernelGGL((gram_tile_kernel<64>), dim3(pairs, nsplit), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, slabs);
-  else
+  else if (f32_only)
     hipLaunchKernelGGL((gram_tile_kernel<128>), dim3(pairs, nsplit), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, slabs);
+  else
+    hipLaunchKernelGGL(gram_planes_kernel, dim3(pairs, nsplit), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, slabs);
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)K * K, 256)), dim3(256), 0, st, slabs, nsplit, Kp, K, B, out);
 }

@@ -33,7 +33,55 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
   }
 }
 
+// General im2col: x [N][H][W][Ci] (channels-last, fp32 or bf16) -> col [N*Ho*Wo][Kp], column ci*kh*kw + r*kw + s =
+// x[n][oh*sh + r - ph][ow*sw + s - pw][ci] (zero outside the image and in the padding columns K .. Kp-1): the row
+// order of weight.reshape(Co, Ci*kh*kw).  With it the per-client weight gradient of ANY convolution geometry is the
+// grouped GEMM gy^T col of linear_wgrad.hip — the route for the kernel sizes / strides conv_wgrad.hip has no tile
+// schedule for (4x4 stride-4 patch embedding of the CVT models, 7x7 / 5x5 tokenizers; reference
+// fllib/models/backbones/cctnets/cvt.py, cct.py).  One thread per output element, columns fastest.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ col, long total, int H, int W,
+                                                     int Ci, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph,
+                                                     int pw, int K, int Kp) {
+  const int kk = kh * kw;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Kp);
+    long pix = i / Kp;
+    const int ow = (int)(pix % Wo);
+    long t = pix / Wo;
+    const int oh = (int)(t % Ho);
+    const long n = t / Ho;
+    T v = (T)0;
+    if (c < K) {
+      const int ci = c / kk, rs = c - ci * kk, r = rs / kw, s = rs - r * kw;
+      const int ih = oh * sh + r - ph, iw = ow * sw + s - pw;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[((n * H + ih) * W + iw) * Ci + ci];
+    }
+    col[i] = v;
+  }
+}
+
 }  // namespace
+
+// col: [N*Ho*Wo][Kp] with Kp >= Ci*kh*kw.  esize 4 (fp32) or 2 (bf16 bits).  returns 0 ok.
+BLADES_API int blades_im2col(const void* x, void* col, long N, int H, int W, int Ci, int Ho, int Wo, int kh, int kw, int sh,
+                             int sw, int ph, int pw, int Kp, int esize, hipStream_t st) {
+  const int K = Ci * kh * kw;
+  if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || Kp < K || Ho <= 0 || Wo <= 0)
+    return 1;
+  const long total = N * Ho * Wo * Kp;
+  long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (esize == 4)
+    hipLaunchKernelGGL((im2col_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)col, total,
+                       H, W, Ci, Ho, Wo, kh, kw, sh, sw, ph, pw, K, Kp);
+  else if (esize == 2)
+    hipLaunchKernelGGL((im2col_kernel<unsigned short>), dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)x,
+                       (unsigned short*)col, total, H, W, Ci, Ho, Wo, kh, kw, sh, sw, ph, pw, K, Kp);
+  else
+    return 2;
+  return 0;
+}
 
 // returns 0 ok; 1 = unsupported shape
 BLADES_API int blades_stem_im2col(const float* x, float* out, int N, int H, int W, int Ci, int k, int pad,

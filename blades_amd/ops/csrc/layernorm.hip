@@ -26,7 +26,7 @@ template <typename T, int NE>
 __global__ __launch_bounds__(TPB) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, long rows, int C, float eps,
                                                      T* __restrict__ y, float* __restrict__ mean,
-                                                     float* __restrict__ rstd) {
+                                                     float* __restrict__ rstd, long gstride, long bstride, int R) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ga[NE], be[NE];
 #pragma unroll
@@ -35,7 +35,19 @@ __global__ __launch_bounds__(TPB) void ln_fwd_kernel(const T* __restrict__ x, co
     ga[j] = (gamma && ch < C) ? gamma[ch] : 1.f;
     be[j] = (beta && ch < C) ? beta[ch] : 0.f;
   }
+  // gstride / bstride != 0: one affine pair per client (local steps > 1: row r belongs to client r / R, whose gamma
+  // starts gstride floats behind the previous client's — rows of the engine's per-client weight matrix)
+  const bool per_client = gstride != 0 || bstride != 0;
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    if (per_client) {
+      const long cl = r / R;
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int ch = j * 64 + lane;
+        ga[j] = (gamma && ch < C) ? gamma[cl * gstride + ch] : 1.f;
+        be[j] = (beta && ch < C) ? beta[cl * bstride + ch] : 0.f;
+      }
+    }
     const T* xr = x + r * C;
     float v[NE], s = 0.f;
 #pragma unroll
@@ -67,7 +79,7 @@ template <typename T, int NE>
 __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int R, int C, int rpc, int nchunk,
-                                                     T* __restrict__ dx, float* __restrict__ partial) {
+                                                     T* __restrict__ dx, float* __restrict__ partial, long gstride) {
   __shared__ float red[4][NE * 64 * 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.y, chunk = blockIdx.x;
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ x, co
 #pragma unroll
   for (int j = 0; j < NE; ++j) {
     const int ch = j * 64 + lane;
-    ga[j] = (gamma && ch < C) ? gamma[ch] : 1.f;
+    ga[j] = (gamma && ch < C) ? gamma[(long)c * gstride + ch] : 1.f;
     dg[j] = 0.f; db[j] = 0.f;
   }
   const int r_lo = chunk * rpc;
@@ -138,18 +150,18 @@ inline int rows_per_chunk(int R) { return R >= 512 ? 128 : (R >= 64 ? 32 : 8); }
 
 template <typename T, int NE>
 void run_fwd(const void* x, const float* gamma, const float* beta, long rows, int C, float eps, void* y, float* mean,
-             float* rstd, hipStream_t st) {
+             float* rstd, long gstride, long bstride, int R, hipStream_t st) {
   int g = cdiv(rows, 4);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL((ln_fwd_kernel<T, NE>), dim3(g), dim3(TPB), 0, st, (const T*)x, gamma, beta, rows, C, eps, (T*)y,
-                     mean, rstd);
+                     mean, rstd, gstride, bstride, R);
 }
 template <typename T, int NE>
 void run_bwd(const void* x, const void* gy, const float* gamma, const float* mean, const float* rstd, int Kc, int R,
-             int C, void* dx, float* partial, hipStream_t st) {
+             int C, void* dx, float* partial, long gstride, hipStream_t st) {
   const int rpc = rows_per_chunk(R), nch = cdiv(R, rpc);
   hipLaunchKernelGGL((ln_bwd_kernel<T, NE>), dim3(nch, Kc), dim3(TPB), 0, st, (const T*)x, (const T*)gy, gamma, mean,
-                     rstd, R, C, rpc, nch, (T*)dx, partial);
+                     rstd, R, C, rpc, nch, (T*)dx, partial, gstride);
 }
 
 }  // namespace
@@ -172,24 +184,40 @@ BLADES_API int blades_ln_nchunk(int R) { return cdiv(R, rows_per_chunk(R)); }
     }                                                                          \
   } while (0)
 
-BLADES_API int blades_ln_forward(const void* x, const float* gamma, const float* beta, long rows, int C, float eps,
-                                 void* y, float* mean, float* rstd, int esize, hipStream_t st) {
+// gstride / bstride: floats between two clients' gamma / beta (0 = one pair shared by all rows); R = rows per client.
+BLADES_API int blades_ln_forward2(const void* x, const float* gamma, const float* beta, long rows, int C, float eps,
+                                  void* y, float* mean, float* rstd, int esize, long gstride, long bstride, int R,
+                                  hipStream_t st) {
   if (rows <= 0 || C <= 0 || C > 1024 || (esize != 2 && esize != 4)) return 1;
-  LN_DISPATCH(run_fwd, x, gamma, beta, rows, C, eps, y, mean, rstd, st);
+  if ((gstride != 0 || bstride != 0) && (R <= 0 || rows % R != 0)) return 3;
+  LN_DISPATCH(run_fwd, x, gamma, beta, rows, C, eps, y, mean, rstd, gstride, bstride, R, st);
   return 0;
 }
 
+BLADES_API int blades_ln_forward(const void* x, const float* gamma, const float* beta, long rows, int C, float eps,
+                                 void* y, float* mean, float* rstd, int esize, hipStream_t st) {
+  return blades_ln_forward2(x, gamma, beta, rows, C, eps, y, mean, rstd, esize, 0, 0, 1, st);
+}
+
 // partial: Kc * nchunk * C * 2 floats.  off_gamma / off_beta < 0: that gradient is not written (no affine parameter).
-BLADES_API int blades_ln_backward(const void* x, const void* gy, const float* gamma, const float* mean,
-                                  const float* rstd, int Kc, int R, int C, const float* coef, float* U, long ld,
-                                  long off_gamma, long off_beta, int accumulate, float* partial, void* dx, int esize,
-                                  hipStream_t st) {
+BLADES_API int blades_ln_backward2(const void* x, const void* gy, const float* gamma, const float* mean,
+                                   const float* rstd, int Kc, int R, int C, const float* coef, float* U, long ld,
+                                   long off_gamma, long off_beta, int accumulate, float* partial, void* dx, int esize,
+                                   long gstride, hipStream_t st) {
   if (Kc <= 0 || R <= 0 || C <= 0 || C > 1024 || Kc > 65535 || (esize != 2 && esize != 4)) return 1;
-  LN_DISPATCH(run_bwd, x, gy, gamma, mean, rstd, Kc, R, C, dx, partial, st);
+  LN_DISPATCH(run_bwd, x, gy, gamma, mean, rstd, Kc, R, C, dx, partial, gstride, st);
   if (U != nullptr && (off_gamma >= 0 || off_beta >= 0)) {
     const int nch = cdiv(R, rows_per_chunk(R));
     hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, coef, U,
                        ld, off_gamma, off_beta, accumulate);
   }
   return 0;
+}
+
+BLADES_API int blades_ln_backward(const void* x, const void* gy, const float* gamma, const float* mean,
+                                  const float* rstd, int Kc, int R, int C, const float* coef, float* U, long ld,
+                                  long off_gamma, long off_beta, int accumulate, float* partial, void* dx, int esize,
+                                  hipStream_t st) {
+  return blades_ln_backward2(x, gy, gamma, mean, rstd, Kc, R, C, coef, U, ld, off_gamma, off_beta, accumulate, partial,
+                             dx, esize, 0, st);
 }

@@ -53,6 +53,62 @@ __global__ __launch_bounds__(TPB) void normal_rows_kernel(float* U, long ld, lon
     p[c] = overwrite ? z : p[c] + z;
   }
 }
+// ---- adversary forges (one pass over the column shard each; reference blades/adversaries/adaptive_adversary.py:32-65,
+// signguard_adversary.py:39-67 build them from half a dozen D-sized torch.where / arithmetic kernels) ----------------
+// Fang-style adaptive attack on Median / TrimmedMean: s = sign(mean), u ~ U(0,1) per coordinate (Philox, global
+// coordinate index), b = 2.
+__global__ __launch_bounds__(TPB) void adaptive_forge_kernel(const float* __restrict__ mean, const float* __restrict__ mn,
+                                                             const float* __restrict__ mx, float* __restrict__ out, long n,
+                                                             unsigned long long offset, uint32_t k0, uint32_t k1,
+                                                             uint32_t stream, float b) {
+  const long stride = (long)gridDim.x * TPB;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+    const float u = philox_uniform_at(offset + i, k0, k1, stream);
+    const float m = mean[i], lo = mn[i], hi = mx[i];
+    float o = 0.f;
+    if (m < 0.f) {
+      if (hi > 0.f) o = hi * (1.f + u * (b - 1.f));
+      else if (hi < 0.f) o = hi * (1.f + u * (1.f / b - 1.f));
+    } else if (m > 0.f) {
+      if (lo > 0.f) o = lo * (1.f / b + u * (1.f - 1.f / b));
+      else if (lo < 0.f) o = lo * (b + u * (1.f - b));
+    } else if (m == 0.f) {
+      o = m;  // (a NaN mean matches no case and gives 0, like the reference's chain of torch.where)
+    }
+    out[i] = o;
+  }
+}
+
+// Sort keys of the SignGuard attack's random permutation: coordinate e gets (31 random bits : 32-bit global index),
+// unique, so "the p coordinates with the smallest keys" is an exact-count uniformly random subset.
+__global__ __launch_bounds__(TPB) void perm_keys_kernel(long* __restrict__ keys, long n, unsigned long long offset,
+                                                        unsigned long long d_valid_end, uint32_t k0, uint32_t k1,
+                                                        uint32_t stream) {
+  const long stride = (long)gridDim.x * TPB;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+    const unsigned long long e = offset + i;
+    const unsigned long long blk = e >> 2;
+    const Philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), stream, 0u, k0, k1);
+    const int lane = (int)(e & 3);
+    const uint32_t x = lane == 0 ? r.x : lane == 1 ? r.y : lane == 2 ? r.z : r.w;
+    // padding columns of a shard (e >= d_valid_end) sort behind every real coordinate
+    keys[i] = e < d_valid_end ? (long)(((unsigned long long)(x >> 1) << 32) | (e & 0xFFFFFFFFull)) : 0x7FFFFFFFFFFFFFFFll;
+  }
+}
+
+// out[i] = +u if key < t[0], -u if key < t[1], else 0 (t = the keys of global rank pos and pos + neg), u ~ U(0,1)
+__global__ __launch_bounds__(TPB) void signguard_forge_kernel(const long* __restrict__ keys, const long* __restrict__ t,
+                                                              float* __restrict__ out, long n, unsigned long long offset,
+                                                              uint32_t k0, uint32_t k1, uint32_t stream) {
+  const long t1 = t[0], t2 = t[1];
+  const long stride = (long)gridDim.x * TPB;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+    const float u = philox_uniform_at(offset + i, k0, k1, stream);
+    const long k = keys[i];
+    out[i] = k < t1 ? u : (k < t2 ? -u : 0.f);
+  }
+}
+
 // Client-keyed dropout multipliers: element e of client uid draws lane e & 3 of Philox counter
 // (e >> 2, uid, tag, c3) — a function of (seed, client, round/step tag, layer) only, so the masks a client sees do
 // not depend on which rank or chunk trains it.  `tag` is read from device memory: a captured HIP graph replays
@@ -127,4 +183,27 @@ BLADES_API void blades_normal_rows(float* U, long ld, long Dl, const long* rows,
   int g = cdiv(Dl, TPB); if (g > 2048) g = 2048;
   hipLaunchKernelGGL(normal_rows_kernel, dim3(g, R), dim3(TPB), 0, st, U, ld, Dl, rows, col_offset, d_total,
                      (uint32_t)seed, (uint32_t)(seed >> 32), stream, mean, std, overwrite);
+}
+
+BLADES_API void blades_adaptive_forge(const float* mean, const float* mn, const float* mx, float* out, long n,
+                                      unsigned long long seed, unsigned stream, unsigned long long offset, float b,
+                                      hipStream_t st) {
+  if (n <= 0) return;
+  int g = cdiv(n, TPB); if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(adaptive_forge_kernel, dim3(g), dim3(TPB), 0, st, mean, mn, mx, out, n, offset, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), stream, b);
+}
+BLADES_API void blades_perm_keys(long* keys, long n, unsigned long long seed, unsigned stream, unsigned long long offset,
+                                 unsigned long long d_valid_end, hipStream_t st) {
+  if (n <= 0) return;
+  int g = cdiv(n, TPB); if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(perm_keys_kernel, dim3(g), dim3(TPB), 0, st, keys, n, offset, d_valid_end, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), stream);
+}
+BLADES_API void blades_signguard_forge(const long* keys, const long* thresholds, float* out, long n,
+                                       unsigned long long seed, unsigned stream, unsigned long long offset, hipStream_t st) {
+  if (n <= 0) return;
+  int g = cdiv(n, TPB); if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(signguard_forge_kernel, dim3(g), dim3(TPB), 0, st, keys, thresholds, out, n, offset, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), stream);
 }

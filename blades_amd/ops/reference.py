@@ -203,6 +203,38 @@ def philox_uniform(n: int, seed: int, stream: int, offset: int = 0, device="cpu"
     return ((x >> 8).to(torch.float32)) * (1.0 / 16777216.0)
 
 
+def adaptive_forge(mean, mn, mx, seed: int, stream: int, offset: int, b: float = 2.0):
+    """Fang et al. attack vector (reference blades/adversaries/adaptive_adversary.py:32-65) from the benign column
+    mean / min / max and one Philox uniform per (global) coordinate."""
+    u = philox_uniform(mean.numel(), seed, stream, offset, device=mean.device)
+    s = torch.sign(mean)
+    out = torch.zeros_like(mean)
+    out = torch.where((s == -1) & (mx > 0), mx * (1 + u * (b - 1)), out)
+    out = torch.where((s == -1) & (mx < 0), mx * (1 + u * (1 / b - 1)), out)
+    out = torch.where((s == 1) & (mn > 0), mn * (1 / b + u * (1 - 1 / b)), out)
+    out = torch.where((s == 1) & (mn < 0), mn * (b + u * (1 - b)), out)
+    return torch.where(s == 0, mean, out)
+
+
+def perm_keys(n: int, seed: int, stream: int, offset: int, d_valid_end: int, device="cpu"):
+    """Unique int64 sort keys of a random permutation of the coordinates: (31 Philox bits : 32-bit global index);
+    padding coordinates (global index >= ``d_valid_end``) get the largest key."""
+    e = torch.arange(offset, offset + n, dtype=torch.int64, device=device)
+    blk = e >> 2
+    c0, c1 = blk & _MASK, (blk >> 32) & _MASK
+    r = _philox4x32(c0, c1, torch.full_like(c0, stream & _MASK), torch.zeros_like(c0), seed & _MASK,
+                    (seed >> 32) & _MASK)
+    lane = e & 3
+    x = torch.where(lane == 0, r[0], torch.where(lane == 1, r[1], torch.where(lane == 2, r[2], r[3])))
+    keys = ((x >> 1) << 32) | (e & _MASK)
+    return torch.where(e < d_valid_end, keys, torch.full_like(keys, 0x7FFFFFFFFFFFFFFF))
+
+
+def signguard_forge(keys, thresholds, seed: int, stream: int, offset: int):
+    u = philox_uniform(keys.numel(), seed, stream, offset, device=keys.device)
+    return torch.where(keys < thresholds[0], u, torch.where(keys < thresholds[1], -u, torch.zeros_like(u)))
+
+
 def client_dropout_mult(uids, n: int, seed: int, tag, layer: int, p: float):
     """``[len(uids), n]`` dropout multipliers (0 or 1/(1-p)), keyed by client: element ``e`` of client ``uid``
     uses lane ``e % 4`` of Philox counter ``(e//4, uid, tag, 2 + 256*layer)``.  ``tag`` (int or 1-element int64

@@ -173,7 +173,8 @@ def test_dp_fedavg_round_on_gpu(tmp_path):
     assert float(torch.nn.functional.cosine_similarity(U[0], U[1], dim=0).abs()) < 0.1
 
 
-@pytest.mark.parametrize("model,ds", [("resnet", "cifar10"), ("cnn", "fashionmnist"), ("mlp", "fashionmnist")])
+@pytest.mark.parametrize("model,ds", [("resnet", "cifar10"), ("cnn", "fashionmnist"), ("mlp", "fashionmnist"),
+                                      ("cct", "cifar10")])
 def test_local_steps_fused_per_client_matches_cpu_oracle(tmp_path, model, ds):
     """Several local steps per round (reference fllib/clients/client.py:55-61): on the GPU the fused executor runs
     with per-client weights — the hand-written convolution / batch-norm / weight-gradient kernels pick each
@@ -201,8 +202,10 @@ def test_local_steps_fused_per_client_matches_cpu_oracle(tmp_path, model, ds):
     # 2 / 4 / 6 clients per chunk moves row 3 between 2e-4 and 7e-3; 1 and 3 streams are bitwise equal), so the
     # bound is on the typical row, not on the best one.  The kernels themselves are held to 1e-6 in test_ops_gpu.
     assert float(rel.median()) < 2e-2 and float(rel.max()) < 1e-1 and float(cos.min()) > 0.995, (rel, cos)
-    if model != "resnet":  # no ReLU behind a strided convolution chain: these stay tight
+    if model not in ("resnet", "cct"):  # no ReLU behind a strided convolution chain: these stay tight
         assert float(rel.max()) < 1e-3, rel
+    if model == "cct":  # per-client LayerNorm / Linear / embeddings all on the fused executor
+        assert float(rel.median()) < 5e-3, rel
 
 
 @pytest.mark.parametrize("model", ["resnet", "resnet18"])
