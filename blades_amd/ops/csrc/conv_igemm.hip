@@ -108,18 +108,23 @@ __device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NPL]) {
 
 // PROF (diagnostic build of one variant, BLADES_IGEMM_PROF=1): s_memtime stamps at the phase boundaries of every
 // wave, summed over the launch into p.prof[16] — where a workgroup's time goes (tools/r3/igemm_prof.py)
-template <int NPL, int MF, bool SPLIT, bool PROF = false>
+// PROF = 2 (BLADES_IGEMM_PROF=2): a light trace instead — four wall-clock stamps per workgroup (entry, loop start,
+// loop end, stores acknowledged; none inside the K loop) plus the shader-clock count of the loop and the hardware ids,
+// one record per tile in p.prof: how the two workgroups of a CU interleave (tools/r3/igemm_trace.py)
+template <int NPL, int MF, bool SPLIT, int PROF = 0>
 __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const IgemmParams p) {
   static_assert(SPLIT || NPL == 1, "bf16 input has a single plane");
   unsigned long long pf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_last = 0;  // (constant indices only: scalar registers)
   auto stamp = [&](const int slot) {
-    if constexpr (PROF) {
+    if constexpr (PROF == 1) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
       pf_t[slot] += now - pf_last;
       pf_last = now;
     }
   };
-  if constexpr (PROF) pf_last = __builtin_amdgcn_s_memtime();
+  if constexpr (PROF == 1) pf_last = __builtin_amdgcn_s_memtime();
+  unsigned long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_c1 = 0, tr_c2 = 0;
+  if constexpr (PROF == 2) tr_t0 = __builtin_amdgcn_s_memrealtime();
   constexpr int MAXPF = max_prefetch(MF);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   __syncthreads();
 
   stamp(0);  // zero fill + synchronous staging of the first chunk / weight tile
+  if constexpr (PROF == 2) { tr_t1 = __builtin_amdgcn_s_memrealtime(); tr_c1 = __builtin_amdgcn_s_memtime(); }
   const unsigned char* Bb0 = B_lds + li * 64 + ((kg * 16) ^ swz(li));
   // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
   // (segment, chunk) pair changes
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     t = tn; c = cn; g = gn; goff_cur = goff_next;
   }
 
+  if constexpr (PROF == 2) { tr_t2 = __builtin_amdgcn_s_memrealtime(); tr_c2 = __builtin_amdgcn_s_memtime(); }
   // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
   const bool vec_out = (p.Co % 4) == 0;
   const bool want_stats = SPLIT && p.stats != nullptr;  // block-uniform
@@ -442,7 +449,18 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
       }
     }
   }
-  if constexpr (PROF) {
+  if constexpr (PROF == 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tr_t3 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && p.prof != nullptr && lid < (1 << 20)) {
+      unsigned long long* r = p.prof + 16 + (size_t)lid * 8;
+      r[0] = tr_t0; r[1] = tr_t1; r[2] = tr_t2; r[3] = tr_t3; r[4] = tr_c2 - tr_c1;
+      r[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+      r[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+      r[7] = blockIdx.x;
+    }
+  }
+  if constexpr (PROF == 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(7);  // epilogue, stores acknowledged
     if (lane == 0 && p.prof != nullptr) {
@@ -570,12 +588,17 @@ int stats_chunks(const IgemmParams& p, int B) {
 }
 
 // BLADES_IGEMM_PROF=1: device buffer of the phase-cycle sums (16 x u64), read and cleared by blades_conv_igemm_prof
+int prof_mode() {
+  static const int m = [] { const char* e = getenv("BLADES_IGEMM_PROF"); return e ? atoi(e) : 0; }();
+  return m == 1 || m == 2 ? m : 0;
+}
+constexpr size_t TRACE_TILES = 1 << 20;  // mode 2: one 8-word record per tile behind the 16 sums
 unsigned long long* prof_buffer() {
   static unsigned long long* buf = [] {
-    const char* e = getenv("BLADES_IGEMM_PROF");
     unsigned long long* b = nullptr;
-    if (e && atoi(e) == 1 && hipMalloc(&b, 16 * sizeof(unsigned long long)) == hipSuccess)
-      (void)hipMemset(b, 0, 16 * sizeof(unsigned long long));
+    const size_t words = 16 + (prof_mode() == 2 ? TRACE_TILES * 8 : 0);
+    if (prof_mode() != 0 && hipMalloc(&b, words * sizeof(unsigned long long)) == hipSuccess)
+      (void)hipMemset(b, 0, words * sizeof(unsigned long long));
     return b;
   }();
   return buf;
@@ -596,13 +619,16 @@ int launch(const IgemmParams& p, hipStream_t st) {
     if (prof_buffer() != nullptr) {
       static bool attr2 = false;
       if (!attr2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<3, MF, true, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<3, MF, true, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / wgs_per_cu(MF));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<3, MF, true, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / wgs_per_cu(MF));
         attr2 = true;
       }
       IgemmParams q = p;
       q.prof = prof_buffer();
-      hipLaunchKernelGGL((conv_igemm_kernel<3, MF, true, true>), dim3(grid), dim3(256), lds, st, q);
+      if (prof_mode() == 2) hipLaunchKernelGGL((conv_igemm_kernel<3, MF, true, 2>), dim3(grid), dim3(256), lds, st, q);
+      else hipLaunchKernelGGL((conv_igemm_kernel<3, MF, true, 1>), dim3(grid), dim3(256), lds, st, q);
       return 0;
     }
   }
@@ -774,6 +800,15 @@ BLADES_API int blades_conv_igemm2(const void* in, const float* w, const float* b
 }
 
 // diagnostics: copies the 16 phase-cycle sums of the PROF kernel to `host` and clears them; 1 = profiling is off
+// mode 2: copies the first `tiles` trace records (8 words each) of the last launch to `host`
+BLADES_API int blades_conv_igemm_trace(unsigned long long* host, long tiles) {
+  unsigned long long* b = prof_buffer();
+  if (b == nullptr || prof_mode() != 2 || tiles > (long)TRACE_TILES) return 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 2;
+  if (hipMemcpy(host, b + 16, (size_t)tiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+  return 0;
+}
+
 BLADES_API int blades_conv_igemm_prof(unsigned long long* host) {
   unsigned long long* b = prof_buffer();
   if (b == nullptr) return 1;

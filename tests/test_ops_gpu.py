@@ -834,12 +834,17 @@ def test_kernels_are_bitwise_deterministic(dev):
     w = torch.rand(K, generator=g).to(dev)
     v = torch.randn(D, generator=g).to(dev)
 
+    def flat(t):
+        if isinstance(t, (tuple, list)):
+            return [u for s in t for u in flat(s)]
+        return [t]
+
     def same(fn, what):
-        a, b = fn(), fn()
-        a = a if isinstance(a, (tuple, list)) else (a,)
-        b = b if isinstance(b, (tuple, list)) else (b,)
+        a, b = flat(fn()), flat(fn())
+        assert len(a) == len(b)
         for i, (x, y) in enumerate(zip(a, b)):
-            if x is None:
+            if not isinstance(x, torch.Tensor):
+                assert x == y, f"{what}[{i}] differs between two runs"
                 continue
             assert torch.equal(x, y), f"{what}[{i}] differs between two runs"
 

@@ -56,6 +56,33 @@ def main():
         except Exception as e:  # noqa: BLE001
             print(f"{name:18s} failed: {type(e).__name__}: {e}", flush=True)
         del W
+    # the update-forging adversaries on the same matrix (rows [0, f) are the malicious clients' rows)
+    from unittest.mock import MagicMock
+
+    from blades_amd import adversaries as ADV
+
+    gcfg = MagicMock()
+    gcfg.num_clients, gcfg.seed = K, 7
+    algo = MagicMock()
+    algo.update_matrix = U
+    mask = torch.ones(K, device=dev)
+    mask[:f] = 0
+    algo.benign_mask = mask
+    algo.malicious_rows = torch.arange(f, device=dev)
+    algo.malicious_row_clients = torch.arange(f)
+    algo.row_clients = torch.arange(K)
+    algo.ctx = ctx
+    algo.server.aggregator = A.Mean()
+    algo.local_results = []
+    for name, kw in [("ALIEAdversary", {}), ("IPMAdversary", {"scale": 0.1}), ("NoiseAdversary", {}),
+                     ("AdaptiveAdversary", {}), ("MinMaxAdversary", {}), ("SignGuardAdversary", {}),
+                     ("AttackclippedclusteringAdversary", {})]:
+        try:
+            adv = getattr(ADV, name)([object()] * f, gcfg, **kw)
+            ms = timeit(lambda: adv.on_local_round_end(algo))
+            print(f"{name:34s} {ms:10.2f} ms", flush=True)
+        except Exception as e:  # noqa: BLE001
+            print(f"{name:34s} failed: {type(e).__name__}: {e}", flush=True)
 
 
 if __name__ == "__main__":
