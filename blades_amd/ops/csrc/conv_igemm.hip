@@ -41,6 +41,10 @@
 #include <cstring>
 #include <cstdlib>
 
+#ifndef BLADES_AF_AHEAD
+#define BLADES_AF_AHEAD 1
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -58,7 +62,7 @@ constexpr int LDS_TOTAL = 160 * 1024;
 // 5.2 ms on the 64-channel layer: the weight-fragment reads per MFMA double)
 constexpr int wgs_per_cu(int) { return 2; }
 // A-staging passes of the next chunk prefetched into registers under the MFMAs
-constexpr int max_prefetch(int) { return 12; }
+constexpr int max_prefetch(int, bool rf = false) { return rf ? 10 : 12; }
 
 struct IgemmParams {
   const void* in;             // [N][Hi][Wi][Ci]
@@ -106,25 +110,12 @@ __device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NPL]) {
   }
 }
 
-// PROF (diagnostic build of one variant, BLADES_IGEMM_PROF=1): s_memtime stamps at the phase boundaries of every
-// wave, summed over the launch into p.prof[16] — where a workgroup's time goes (tools/r3/igemm_prof.py)
-// PROF = 2 (BLADES_IGEMM_PROF=2): a light trace instead — four wall-clock stamps per workgroup (entry, loop start,
-// loop end, stores acknowledged; none inside the K loop) plus the shader-clock count of the loop and the hardware ids,
-// one record per tile in p.prof: how the two workgroups of a CU interleave (tools/r3/igemm_trace.py)
-template <int NPL, int MF, bool SPLIT, int PROF = 0>
-__global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const IgemmParams p) {
+// The LDS-staged weight tile kernel (rounds 2-3), kept as it was for the geometries where it is the faster one; the
+// generalised kernel below adds the register-fed weight path (RF) and the diagnostic builds.
+template <int NPL, int MF, bool SPLIT>
+__global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_v1_kernel(const IgemmParams p) {
   static_assert(SPLIT || NPL == 1, "bf16 input has a single plane");
-  unsigned long long pf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_last = 0;  // (constant indices only: scalar registers)
-  auto stamp = [&](const int slot) {
-    if constexpr (PROF == 1) {
-      const unsigned long long now = __builtin_amdgcn_s_memtime();
-      pf_t[slot] += now - pf_last;
-      pf_last = now;
-    }
-  };
-  if constexpr (PROF == 1) pf_last = __builtin_amdgcn_s_memtime();
-  unsigned long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_c1 = 0, tr_c2 = 0;
-  if constexpr (PROF == 2) tr_t0 = __builtin_amdgcn_s_memrealtime();
+  auto stamp = [](const int) {};
   constexpr int MAXPF = max_prefetch(MF);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,9 +231,13 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   };
   // B: weight tile of one step = NPL x [64 co][32 ci]; thread -> (co row tid >> 2, 8-channel group tid & 3)
   const int brow = tid >> 2, bkg = tid & 3;
-  const size_t w_plane = (size_t)p.ntw * p.Cop * p.Cip;
+  // (global planes are in fragment order, see conv_wprep_kernel: a thread's 16 bytes of plane q sit q KiB x 2 apart)
+  const int nchunks_w = p.Cip / KC;
+  const unsigned short* wsrc = wp_c + (size_t)nt * (2 * NPL * 2 * 64 * 8) +
+                               ((((brow >> 5) * NPL) * 2 + ((brow >> 4) & 1)) * 64 + bkg * 16 + (brow & 15)) * 8;
   auto b_load = [&](int tw, int c0, int q) {
-    return *reinterpret_cast<const u32x4*>(wp_c + q * w_plane + ((size_t)tw * p.Cop + n0 + brow) * p.Cip + c0 + bkg * 8);
+    return *reinterpret_cast<const u32x4*>(wsrc + ((size_t)tw * nchunks_w + (c0 >> 5)) * p.n_ntiles * (2 * NPL * 2 * 64 * 8) +
+                                           q * (2 * 64 * 8));
   };
   const int b_dst = brow * 64 + ((bkg * 16) ^ swz(brow));
   const int b_img = p.bdouble ? NPL * b_plane : 0;  // distance between the two weight-tile images
@@ -266,7 +261,6 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   __syncthreads();
 
   stamp(0);  // zero fill + synchronous staging of the first chunk / weight tile
-  if constexpr (PROF == 2) { tr_t1 = __builtin_amdgcn_s_memrealtime(); tr_c1 = __builtin_amdgcn_s_memtime(); }
   const unsigned char* Bb0 = B_lds + li * 64 + ((kg * 16) ^ swz(li));
   // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
   // (segment, chunk) pair changes
@@ -366,7 +360,6 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
     t = tn; c = cn; g = gn; goff_cur = goff_next;
   }
 
-  if constexpr (PROF == 2) { tr_t2 = __builtin_amdgcn_s_memrealtime(); tr_c2 = __builtin_amdgcn_s_memtime(); }
   // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
   const bool vec_out = (p.Co % 4) == 0;
   const bool want_stats = SPLIT && p.stats != nullptr;  // block-uniform
@@ -449,6 +442,444 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
       }
     }
   }
+}
+
+
+// PROF (diagnostic build of one variant, BLADES_IGEMM_PROF=1): s_memtime stamps at the phase boundaries of every
+// wave, summed over the launch into p.prof[16] — where a workgroup's time goes (tools/r3/igemm_prof.py)
+// PROF = 2 (BLADES_IGEMM_PROF=2): a light trace instead — four wall-clock stamps per workgroup (entry, loop start,
+// loop end, stores acknowledged; none inside the K loop) plus the shader-clock count of the loop and the hardware ids,
+// one record per tile in p.prof: how the two workgroups of a CU interleave (tools/r3/igemm_trace.py)
+// RF ("register-fed weights", the default): the four waves own (pixel half, 32-channel half) quarters of the tile
+// instead of pixel quarters.  A wave then needs only ITS 32 output channels of a step's weight tile — 2 fragments x
+// NPL planes — and loads them straight from global memory into registers, one step ahead, from weight planes that
+// conv_wprep_kernel stores in fragment order (1 KiB per wave instruction, L1/L2 resident: all four waves of both
+// workgroups of a CU and every tile of the launch read the same few KiB).  No weight tile in LDS, no LDS stores and
+// no barrier per step: workgroup barriers remain only around the input restage at a chunk boundary (every `taps`
+// steps).  LDS fragment reads per MFMA are unchanged (24 per 96).  RF = false keeps the LDS-staged weight tile.
+template <int NPL, int MF, bool SPLIT, int PROF = 0, bool RF = false>
+__global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const IgemmParams p) {
+  static_assert(SPLIT || NPL == 1, "bf16 input has a single plane");
+  constexpr int NPF = RF ? 2 * MF : MF;  // pixel fragments per wave
+  constexpr int NCF = RF ? 2 : 4;        // channel fragments per wave
+  unsigned long long pf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_last = 0;  // (constant indices only: scalar registers)
+  auto stamp = [&](const int slot) {
+    if constexpr (PROF == 1) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      pf_t[slot] += now - pf_last;
+      pf_last = now;
+    }
+  };
+  if constexpr (PROF == 1) pf_last = __builtin_amdgcn_s_memtime();
+  unsigned long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_c1 = 0, tr_c2 = 0;
+  if constexpr (PROF == 2) tr_t0 = __builtin_amdgcn_s_memrealtime();
+  constexpr int MAXPF = max_prefetch(MF, RF);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_xcd = gridDim.x >> 3;
+  const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (lid >= p.n_mtiles * p.n_ntiles) return;  // whole workgroup leaves: no barrier is skipped by a subset
+  const int nt = lid % p.n_ntiles, mt = lid / p.n_ntiles;
+  const int n0 = nt * BN;
+  int img0, sy0;
+  if (p.TI == 1) { img0 = mt / p.tiles_per_img; sy0 = (mt - img0 * p.tiles_per_img) * p.TR; }
+  else { img0 = mt * p.TI; sy0 = 0; }
+  const int iy_lo = sy0 * p.si + p.aymin;
+  // per-client weights: a tile never straddles two clients (plan() keeps TI a divisor of imgs_per_client)
+  const int client = p.n_clients > 1 ? img0 / p.imgs_per_client : 0;
+  const unsigned short* wp_c = p.wp + (size_t)client * p.wp_client_stride;
+  const float* bias_c = p.bias ? p.bias + (size_t)client * p.bias_client_stride : nullptr;
+
+  const int a_plane = p.NS * 64, a_buf = NPL * a_plane;
+  constexpr int b_plane = BN * 64;
+  unsigned char* A_lds = smem;          // [NPL][NS slots][32 ch] bf16
+  unsigned char* B_lds = smem + a_buf;  // [NPL][64 co][32 ci] bf16
+  for (int i = tid * 16; i < a_buf; i += 256 * 16) *reinterpret_cast<u32x4*>(A_lds + i) = u32x4{0, 0, 0, 0};
+
+  // Both LDS images have 64-byte rows (32 channels of one slot / one output channel).  A fragment read
+  // (ds_read_b128: lane -> row li, 16-byte channel group kg) of 16 consecutive rows would put four lanes of
+  // every 16-lane service group on the same banks; XOR-ing bit 1 of the channel group with bit 2 of the row
+  // makes those reads conflict-free.  Stores apply the same involution.
+  auto swz = [](int row) { return (row & 4) << 3; };
+
+  // ---- this lane's output pixels: fragment pf, column li ---------------------------------------------------
+  const int li = lane & 15, kg = lane >> 4;
+  const int wpix = RF ? (wave & 1) : wave;      // which NPF*16-pixel group of the tile
+  const int cbase = RF ? (wave >> 1) * 32 : 0;  // first output channel of the wave inside the tile
+  int a_slot[NPF];
+  // (the output pixel index is only needed by the epilogue and is recomputed there: nothing of it lives through the
+  // K loop)
+  auto pixel_of = [&](int pf, int& slot) -> long {
+    const int m = (wpix * NPF + pf) * 16 + li;
+    const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
+    const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
+    const bool ok = il < p.TI && sy0 + ry < p.Hs && img0 + il < p.N;
+    slot = ok ? il * p.IS + ry * p.si * p.WS + sx * p.si + p.PL : p.PL;
+    return ok ? ((long)(img0 + il) * p.Hout + (sy0 + ry) * p.so + p.poy) * p.Wout + sx * p.so + p.pox : -1;
+  };
+#pragma unroll
+  for (int pf = 0; pf < NPF; ++pf) (void)pixel_of(pf, a_slot[pf]);
+
+  // ---- staging roles -----------------------------------------------------------------------------------------
+  // A: one pass = PIXPP region pixels x 32 channels; lane group (cg) covers CPL channels of a pixel (16 bytes)
+  constexpr int CPL = SPLIT ? 4 : 8, LPP = KC / CPL, PIXPP = 256 / LPP;
+  const int cg = tid % LPP, pp = tid / LPP;
+  struct ADesc { long goff; int slot; };
+  auto a_desc = [&](int pass, long seg_goff, int pp_in = -1) {
+    ADesc d;
+    const int e = pass * PIXPP + (pp_in < 0 ? pp : pp_in);
+    const int il = fdiv(e, p.inv_irwi), rem = e - il * p.IR * p.Wi;
+    const int r = fdiv(rem, p.inv_wi), ix = rem - r * p.Wi;
+    const int iy = iy_lo + r;
+    const bool ok = e < p.region_px && (unsigned)iy < (unsigned)p.Hi && img0 + il < p.N;
+    d.slot = il * p.IS + r * p.WS + ix + p.PL;
+    d.goff = ok ? (((long)(img0 + il) * p.Hphys + (long)iy * p.in_rm) * p.Wphys + (long)ix * p.in_cm) * p.Ci + seg_goff
+                : -1;
+    return d;
+  };
+  const bool vec_in = (p.Ci % CPL) == 0;
+  auto a_load = [&](const ADesc& d, int c0) {
+    u32x4 v = {0, 0, 0, 0};
+    const int ch = c0 + cg * CPL;
+    if (d.goff >= 0 && ch < p.Ci) {
+      if constexpr (SPLIT) {
+        const float* src = reinterpret_cast<const float*>(p.in) + d.goff + ch;
+        if (vec_in) v = *reinterpret_cast<const u32x4*>(src);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ch + j < p.Ci ? __float_as_uint(src[j]) : 0u;
+        }
+      } else {
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(p.in) + d.goff + ch;
+        if (vec_in) v = *reinterpret_cast<const u32x4*>(src);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned e = ch + j < p.Ci ? src[j] : 0u;
+            v[j >> 1] |= e << ((j & 1) * 16);
+          }
+        }
+      }
+    }
+    return v;
+  };
+  auto a_store = [&](const ADesc& d, u32x4 v) {
+    if (d.goff < 0) return;  // outside the image / region: the slot keeps its zero fill
+    if constexpr (SPLIT) {
+      unsigned char* dst = A_lds + d.slot * 64 + (((cg >> 1) * 16) ^ swz(d.slot)) + (cg & 1) * 8;
+      u32x2 pl[NPL];
+      split4<NPL>(__builtin_bit_cast(f32x4, v), pl);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(dst + q * a_plane) = pl[q];
+    } else {
+      *reinterpret_cast<u32x4*>(A_lds + d.slot * 64 + ((cg * 16) ^ swz(d.slot))) = v;
+    }
+  };
+  // whole-chunk staging with every load of a batch in flight before the first conversion
+  auto a_stage_sync = [&](int pass_begin, int c0, long seg) {
+    for (int j0 = pass_begin; j0 < p.npass; j0 += 4) {
+      ADesc d[4];
+      u32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d[j].goff = -1; d[j].slot = 0;
+        if (j0 + j < p.npass) d[j] = a_desc(j0 + j, seg);
+        v[j] = a_load(d[j], c0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a_store(d[j], v[j]);
+    }
+  };
+  // B: weight tile of one step = NPL x [64 co][32 ci]; thread -> (co row tid >> 2, 8-channel group tid & 3)
+  // global weight planes are in fragment order (conv_wprep_kernel): one (tap, chunk, channel tile) = 2 halves x NPL
+  // planes x 2 fragments x [64 lanes][8 bf16]
+  const int brow = tid >> 2, bkg = tid & 3;
+  const int nchunks = p.Cip / KC;
+  constexpr size_t frag_tile = (size_t)2 * NPL * 2 * 64 * 8;
+  auto wtile = [&](int tw, int cchunk) {
+    return wp_c + (((size_t)tw * nchunks + cchunk) * p.n_ntiles + nt) * frag_tile;
+  };
+  const int b_src = ((((brow >> 5) * NPL) * 2 + ((brow >> 4) & 1)) * 64 + bkg * 16 + (brow & 15)) * 8;
+  auto b_load = [&](int tw, int c0, int q) {
+    return *reinterpret_cast<const u32x4*>(wtile(tw, c0 / KC) + b_src + q * (2 * 64 * 8));
+  };
+  const int rf_src = ((wave >> 1) * NPL * 2 * 64 + lane) * 8;
+  auto rf_load = [&](bf16x8 (&w)[NPL][NCF], int tw, int cchunk) {
+    const unsigned short* b = wtile(tw, cchunk) + rf_src;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q)
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf) w[q][cf] = *reinterpret_cast<const bf16x8*>(b + (q * 2 + cf) * (64 * 8));
+  };
+  const int b_dst = brow * 64 + ((bkg * 16) ^ swz(brow));
+  const int b_img = p.bdouble ? NPL * b_plane : 0;  // distance between the two weight-tile images
+  auto b_store = [&](u32x4 v, int q, int img) {
+    *reinterpret_cast<u32x4*>(B_lds + img * b_img + q * b_plane + b_dst) = v;
+  };
+
+  f32x4 acc[NPF][NCF];
+#pragma unroll
+  for (int pf = 0; pf < NPF; ++pf)
+#pragma unroll
+    for (int cf = 0; cf < NCF; ++cf) acc[pf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = nchunks * p.ntaps;
+  bf16x8 wfa[NPL][NCF], wfb[NPL][NCF];  // RF: this step's / the next step's weight fragments (ping-pong)
+  __syncthreads();  // zero fill complete
+  if (nsteps > 0) {
+    if constexpr (RF) rf_load(wfa, p.tap_w[0], 0);
+    a_stage_sync(0, 0, p.seg_goff[0]);
+    if constexpr (!RF) {
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q, 0);
+    }
+  }
+  __syncthreads();
+
+  stamp(0);  // zero fill + synchronous staging of the first chunk / weight tile
+  if constexpr (PROF == 2) { tr_t1 = __builtin_amdgcn_s_memrealtime(); tr_c1 = __builtin_amdgcn_s_memtime(); }
+  const unsigned char* Bb0 = B_lds + li * 64 + ((kg * 16) ^ swz(li));
+  // step order: segment, then 32-channel chunk, then the segment's taps; the input tile is restaged whenever the
+  // (segment, chunk) pair changes
+  int g = 0, c = 0, t = 0;
+  long goff_cur = p.seg_goff[0];
+  // The tap tables live in one register each (lane i holds entry i) and are read with v_readlane: a kernel-argument
+  // load indexed by the step's tap has the latency of a cache access, shares its counter with the LDS reads, and sat
+  // in front of every step's weight prefetch and fragment-read burst.
+  static_assert(MAXTAPS <= 64, "one lane per tap");
+  const int lane_toff = p.tap_off[lane < MAXTAPS ? lane : 0], lane_tw = p.tap_w[lane < MAXTAPS ? lane : 0];
+  int seg_lo = p.seg_begin[0], seg_hi = p.seg_begin[1];  // taps of segment g (kept in registers: a kernel-argument
+                                                         // load per step shows in the short steps of the bf16 kernels)
+  bf16x8 af[NPL];  // activation fragment 0 of the coming step (read ahead)
+  auto a_frag = [&](bf16x8 (&f)[NPL], int pf, int toff) {
+    const int s = a_slot[pf] + toff;
+    const unsigned char* Ab = A_lds + s * 64 + ((kg * 16) ^ swz(s));
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) f[q] = *reinterpret_cast<const bf16x8*>(Ab + q * a_plane);
+  };
+#if BLADES_AF_AHEAD
+  if (nsteps > 0) a_frag(af, 0, __builtin_amdgcn_readlane(lane_toff, seg_lo));
+#endif
+  // one K-step; RF: `wc` holds this step's weight fragments, `wn` receives the next step's (the caller alternates them)
+  auto do_step = [&](bf16x8 (&wc)[NPL][NCF], bf16x8 (&wn)[NPL][NCF], const int ks) {
+    int tn = t + 1, cn = c, gn = g;
+    if (tn == seg_hi) {
+      tn = seg_lo; cn = c + 1;
+      if (cn == nchunks) { cn = 0; gn = g + 1; tn = seg_hi; }
+    }
+    const bool more = ks + 1 < nsteps;
+    const bool next_b = more && !(p.ablate & (1 | 8));  // bit 3 (timing only, wrong results): no weight staging and
+                                                       // no barriers inside a chunk = bound of a register-fed B path
+    const bool next_a = more && (cn != c || gn != g) && !(p.ablate & (1 | 32));  // this step ends (g, c): restage A after it
+    long goff_next = goff_cur;
+    if (gn != g && more) goff_next = p.seg_goff[gn];
+    const int toff = __builtin_amdgcn_readlane(lane_toff, t);
+    // 1. global loads: next step's weight tile / fragments; at a chunk's last tap also the next chunk of the input
+    //    tile.  They complete under this step's MFMAs (and under the MFMAs of the workgroup sharing the CU).
+    u32x4 breg[NPL];
+    if (next_b) {
+      const int tw = __builtin_amdgcn_readlane(lane_tw, tn);
+      if constexpr (RF) rf_load(wn, tw, cn);
+      else {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) breg[q] = b_load(tw, cn * KC, q);
+      }
+    }
+    u32x4 areg[MAXPF];
+    if (next_a) {
+#pragma unroll
+      for (int j = 0; j < MAXPF; ++j) {
+        areg[j] = u32x4{0, 0, 0, 0};
+        if (j < p.npass) areg[j] = a_load(a_desc(j, goff_next), cn * KC);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(1);  // address arithmetic + issue of the global loads
+    // 2. MFMAs of (chunk c, tap t)
+    if (!(p.ablate & 4)) {
+      bf16x8 wl[NPL][NCF];
+      if constexpr (!RF) {
+        const unsigned char* Bb = Bb0 + (ks & 1) * b_img;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q)
+#pragma unroll
+          for (int cf = 0; cf < NCF; ++cf) wl[q][cf] = *reinterpret_cast<const bf16x8*>(Bb + q * b_plane + cf * 1024);
+      }
+      auto& wf = [&]() -> bf16x8 (&)[NPL][NCF] { if constexpr (RF) return wc; else return wl; }();
+      // activation fragments are read one fragment ahead of the MFMAs that use them (the compiler keeps the source
+      // order of LDS reads and MFMAs: read-then-multiply per fragment exposed the LDS latency eight times a step);
+      // the first fragment of the NEXT step is read behind the last MFMAs of this one unless the tile is restaged
+      const int toff_n = __builtin_amdgcn_readlane(lane_toff, tn);
+#pragma unroll
+      for (int pf = 0; pf < NPF; ++pf) {
+        bf16x8 afn[NPL];
+#if BLADES_AF_AHEAD
+        if (pf + 1 < NPF) a_frag(afn, pf + 1, toff);
+        else if (more && !next_a) a_frag(afn, 0, toff_n);
+#else
+        (void)toff_n;
+        a_frag(af, pf, toff);
+#endif
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) {
+          // (weight plane, activation plane) pairs, small terms first
+          if constexpr (NPL == 3) {
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[1], acc[pf][cf], 0, 0, 0);
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[2], acc[pf][cf], 0, 0, 0);
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][cf], af[0], acc[pf][cf], 0, 0, 0);
+          }
+          if constexpr (NPL >= 2) {
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[1], acc[pf][cf], 0, 0, 0);
+            acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][cf], af[0], acc[pf][cf], 0, 0, 0);
+          }
+          acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][cf], af[0], acc[pf][cf], 0, 0, 0);
+        }
+#if BLADES_AF_AHEAD
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) af[q] = afn[q];
+#endif
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(2);  // fragment reads + MFMA issue
+    const bool sync_b = !RF && !(p.ablate & 8);  // the LDS-staged weight tile needs the workgroup every step
+    if (sync_b || next_a) {
+      // every wave has read this step's fragments — not needed for the weight tile alone when it goes to the other
+      // image (its last readers finished before the barrier that ended the previous step)
+      if (!p.bdouble || next_a || RF) __syncthreads();
+      stamp(3);  // first barrier
+      // 3. commit the staged data
+      if constexpr (!RF) {
+        if (next_b && !(p.ablate & 2)) {
+#pragma unroll
+          for (int q = 0; q < NPL; ++q) b_store(breg[q], q, (ks + 1) & 1);
+        }
+      }
+      if (next_a && !(p.ablate & 2)) {
+        // the descriptors are recomputed rather than kept from the load (an opaque copy of the offset stops the
+        // compiler from keeping three registers per pass alive through the MFMAs)
+        int pp_c = pp;
+        if constexpr (RF) asm volatile("" : "+v"(pp_c));
+#pragma unroll
+        for (int j = 0; j < MAXPF; ++j)
+          if (j < p.npass) a_store(a_desc(j, goff_next, pp_c), areg[j]);
+        a_stage_sync(MAXPF, cn * KC, goff_next);  // geometries with more than MAXPF passes: the rest without prefetch
+      }
+      if (next_a) stamp(5); else stamp(4);  // commit: wait for the loads, split, LDS stores (4: weight tile only)
+      __syncthreads();
+      stamp(6);  // second barrier
+#if BLADES_AF_AHEAD
+      if (next_a && !(p.ablate & 4)) a_frag(af, 0, __builtin_amdgcn_readlane(lane_toff, tn));
+#endif
+    }
+    if (gn != g && more) { seg_lo = seg_hi; seg_hi = p.seg_begin[gn + 1]; }
+    t = tn; c = cn; g = gn; goff_cur = goff_next;
+  };
+  if constexpr (RF) {
+#ifndef BLADES_RF_UNROLL
+    for (int ks = 0; ks < nsteps; ++ks) {
+      do_step(wfa, wfb, ks);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) wfa[q][cf] = wfb[q][cf];
+    }
+#else
+    for (int ks = 0; ks < nsteps; ks += 2) {
+      do_step(wfa, wfb, ks);
+      if (ks + 1 < nsteps) do_step(wfb, wfa, ks + 1);
+    }
+#endif
+  } else {
+    for (int ks = 0; ks < nsteps; ++ks) do_step(wfa, wfa, ks);
+  }
+
+  if constexpr (PROF == 2) { tr_t2 = __builtin_amdgcn_s_memrealtime(); tr_c2 = __builtin_amdgcn_s_memtime(); }
+  // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
+  const bool vec_out = (p.Co % 4) == 0;
+  const bool want_stats = SPLIT && p.stats != nullptr;  // block-uniform
+  f32x4 st_s[NCF], st_q[NCF];
+#pragma unroll
+  for (int cf = 0; cf < NCF; ++cf) { st_s[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; st_q[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int pf = 0; pf < NPF; ++pf) {
+    int slot_unused;
+    const long out_pix_pf = pixel_of(pf, slot_unused);
+    if (out_pix_pf < 0) continue;
+#pragma unroll
+    for (int cf = 0; cf < NCF; ++cf) {
+      const int co = n0 + cbase + cf * 16 + kg * 4;
+      if (co >= p.Co) continue;
+      f32x4 v = acc[pf][cf];
+      if (bias_c != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? bias_c[co + j] : 0.f;
+      }
+      if (want_stats) { st_s[cf] += v; st_q[cf] += v * v; }
+      if constexpr (SPLIT) {
+        float* dst = reinterpret_cast<float*>(p.out) + out_pix_pf * p.Co + co;
+        if (vec_out) {
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+        }
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(p.out) + out_pix_pf * p.Co + co;
+        if (p.accumulate) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.Co) v[j] += __uint_as_float((unsigned)dst[j] << 16);
+        }
+        const u32x2 b = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+        if (vec_out) *reinterpret_cast<u32x2*>(dst) = b;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = (unsigned short)(b[j >> 1] >> ((j & 1) * 16));
+        }
+      }
+    }
+  }
+  if constexpr (SPLIT) {
+    if (want_stats) {
+      // BatchNorm statistics of this tile: fixed-order tree over the 16 pixel lanes, then over the waves that hold
+      // the channel (all four; RF: the two pixel halves) through LDS
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            st_s[cf][j] += __shfl_xor(st_s[cf][j], o);
+            st_q[cf][j] += __shfl_xor(st_q[cf][j], o);
+          }
+      __syncthreads();  // every wave is past its last fragment read (RF has no barrier at the end of the K loop)
+      float* red = reinterpret_cast<float*>(smem);  // [pixel groups][64 ch][2]
+      if (li == 0) {
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ch = cbase + cf * 16 + kg * 4 + j;
+            red[(wpix * 64 + ch) * 2 + 0] = st_s[cf][j];
+            red[(wpix * 64 + ch) * 2 + 1] = st_q[cf][j];
+          }
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int ch = tid >> 1, which = tid & 1;
+        if (n0 + ch < p.Co) {
+          float a = 0.f;
+#pragma unroll
+          for (int w = 0; w < (RF ? 2 : 4); ++w) a += red[(w * 64 + ch) * 2 + which];
+          const int cl = img0 / p.stats_B, in_cl = img0 - cl * p.stats_B;
+          const int chunk = p.TI == 1 ? in_cl * p.tiles_per_img + (mt - img0 * p.tiles_per_img) : in_cl / p.TI;
+          p.stats[(((size_t)cl * p.stats_nchunk + chunk) * p.Co + n0 + ch) * 2 + which] = a;
+        }
+      }
+    }
+  }
   if constexpr (PROF == 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long tr_t3 = __builtin_amdgcn_s_memrealtime();
@@ -471,27 +902,35 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   }
 }
 
-// Weight planes.  w is the PyTorch tensor [Co][Ci][taps] (fp32, contiguous).  transpose = 0 (forward):
-// wp[q][t][co][ci]; transpose = 1 (data gradient: the produced channels are the layer's input channels):
-// wp[q][t][ci][co].  Rows / columns beyond the real channel counts are zero.
+// Weight planes.  w is the PyTorch tensor [Co][Ci][taps] (fp32, contiguous).  With rows = produced channels and
+// k = reduced channels (forward: rows = Co, k = Ci; transpose = 1, data gradient: rows = Ci, k = Co), padded to
+// multiples of 64 / 32 with zeros, the planes are stored in the order the kernels consume them:
+//   [tap][32-wide k chunk][64-row tile][32-row half][plane][16-row fragment][lane = (k % 32 / 8) * 16 + row % 16][k % 8]
+// i.e. one (tap, chunk, tile) is 2 x NPL x 2 MFMA A-operand fragments of 1 KiB, each read by one wave instruction.
 __global__ __launch_bounds__(256) void conv_wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
                                                          int Co, int Ci, int taps, int rows, int rows_pad, int k,
                                                          int k_pad, int transpose, int npl, long w_client_stride) {
   const size_t total = (size_t)taps * rows_pad * k_pad;
-  w += (size_t)blockIdx.y * w_client_stride;          // one weight set per client (grid.y), planes [client][npl][..]
+  w += (size_t)blockIdx.y * w_client_stride;          // one weight set per client (grid.y), planes [client][..]
   wp += (size_t)blockIdx.y * npl * total;
+  const int nchunks = k_pad / KC, ntiles = rows_pad / BN;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int kk = (int)(i % k_pad);
-    const size_t rr = i / k_pad;
-    const int row = (int)(rr % rows_pad), t = (int)(rr / rows_pad);
+    // i enumerates the destination order without the plane index: (t, chunk, tile, half, frag, lane, e)
+    const int e = (int)(i & 7), ln = (int)((i >> 3) & 63), frag = (int)((i >> 9) & 1), half = (int)((i >> 10) & 1);
+    size_t r = i >> 11;
+    const int tile = (int)(r % ntiles); r /= ntiles;
+    const int chunk = (int)(r % nchunks);
+    const int t = (int)(r / nchunks);
+    const int row = tile * BN + half * 32 + frag * 16 + (ln & 15), kk = chunk * KC + (ln >> 4) * 8 + e;
     float v = 0.f;
     if (row < rows && kk < k) {
       const int co = transpose ? kk : row, ci = transpose ? row : kk;
       v = w[((size_t)co * Ci + ci) * taps + t];
     }
+    const size_t grp = i >> 10;  // (t, chunk, tile, half)
     for (int q = 0; q < npl; ++q) {
       const __bf16 b = (__bf16)v;
-      wp[q * total + i] = __builtin_bit_cast(unsigned short, b);
+      wp[((grp * npl + q) * 2 + frag) * 512 + (size_t)ln * 8 + e] = __builtin_bit_cast(unsigned short, b);
       v -= (float)b;
     }
   }
@@ -499,13 +938,33 @@ __global__ __launch_bounds__(256) void conv_wprep_kernel(const float* __restrict
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// BLADES_IGEMM_RF: 1 = register-fed weights everywhere, 0 = nowhere; default: where the LDS that the weight tile no
+// longer takes buys a larger pixel tile (the 4x4 / 512-channel layers: 256 instead of 128 pixels, measured -12 %;
+// at equal tile size the two paths measured within 1-2 % of each other on the stride-1 layers and the LDS-staged
+// one faster on the short chunks of the strided segments: profiles/r3_conv_igemm_rf_ab_same_box.log)
+inline int rf_mode() {
+  static const int m = [] { const char* e = getenv("BLADES_IGEMM_RF"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  return m;
+}
+
+// tile choice over both weight paths; sets `rf`
+int plan(IgemmParams& p, int npl, const int* ay, const int* ax, bool rf);
+int choose(IgemmParams& p, int npl, const int* ay, const int* ax, bool& rf) {
+  IgemmParams a = p, b = p;
+  const int mf_lds = rf_mode() == 1 ? 0 : plan(a, npl, ay, ax, false);
+  const int mf_rf = rf_mode() == 0 ? 0 : plan(b, npl, ay, ax, true);
+  rf = mf_rf > mf_lds;
+  p = rf ? b : a;
+  return rf ? mf_rf : mf_lds;
+}
+
 inline bool no_bdouble() {
   static const bool off = [] { const char* e = getenv("BLADES_IGEMM_BDOUBLE"); return e && atoi(e) == 0; }();
   return off;
 }
 
 // Tile choice + geometry for one launch.  Returns the number of pixel fragments per wave (4, 2, 1), 0 = no fit.
-int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
+int plan(IgemmParams& p, int npl, const int* ay, const int* ax, bool rf) {
   int aymin = 0, aymax = 0, axmin = 0, axmax = 0;
   for (int t = 0; t < p.ntaps; ++t) {
     if (t == 0 || ay[t] < aymin) aymin = ay[t];
@@ -553,9 +1012,9 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax) {
       const int rows = q.TI > 1 ? (q.TI - 1) * (q.IR - share) + q.IR : q.IR;
       q.IS = q.TI > 1 ? (q.IR - share) * p.WS : q.IR * p.WS;
       q.NS = round_up(rows * p.WS + hpad + p.PL + 1, 4);
-      long lds = (long)npl * q.NS * 64 + 2L * npl * BN * 64;
-      q.bdouble = 1;
-      if (lds > LDS_TOTAL / wgs_per_cu(mf) || no_bdouble()) { lds -= (long)npl * BN * 64; q.bdouble = 0; }
+      long lds = (long)npl * q.NS * 64 + (rf ? 0L : 2L * npl * BN * 64);
+      q.bdouble = rf ? 0 : 1;
+      if (!rf && (lds > LDS_TOTAL / wgs_per_cu(mf) || no_bdouble())) { lds -= (long)npl * BN * 64; q.bdouble = 0; }
       q.region_px = q.TI * q.IR * p.Wi;
       const bool fits = lds <= LDS_TOTAL / wgs_per_cu(mf) && q.region_px < (1 << 20) && p.Wi < 4096 && q.IR * p.Wi < 4096 * 64;
       if (fits) {
@@ -604,40 +1063,45 @@ unsigned long long* prof_buffer() {
   return buf;
 }
 
-template <int NPL, int MF, bool SPLIT>
-int launch(const IgemmParams& p, hipStream_t st) {
-  const size_t lds = (size_t)NPL * p.NS * 64 + (size_t)(p.bdouble ? 2 : 1) * NPL * BN * 64;
+template <int NPL, int MF, bool SPLIT, int PROF, bool RF>
+void launch1(const IgemmParams& p, int grid, size_t lds, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<NPL, MF, SPLIT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<NPL, MF, SPLIT, PROF, RF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / wgs_per_cu(MF));
     attr = true;
   }
+  hipLaunchKernelGGL((conv_igemm_kernel<NPL, MF, SPLIT, PROF, RF>), dim3(grid), dim3(256), lds, st, p);
+}
+
+template <int NPL, int MF, bool SPLIT>
+int launch(const IgemmParams& p, hipStream_t st, bool rf) {
+  const size_t lds = (size_t)NPL * p.NS * 64 + (rf ? 0 : (size_t)(p.bdouble ? 2 : 1) * NPL * BN * 64);
   const int blocks = p.n_mtiles * p.n_ntiles;
   const int grid = (blocks + 7) / 8 * 8;
   if constexpr (NPL == 3 && MF >= 2 && SPLIT) {
     if (prof_buffer() != nullptr) {
-      static bool attr2 = false;
-      if (!attr2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<3, MF, true, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / wgs_per_cu(MF));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<3, MF, true, 2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / wgs_per_cu(MF));
-        attr2 = true;
-      }
       IgemmParams q = p;
       q.prof = prof_buffer();
-      if (prof_mode() == 2) hipLaunchKernelGGL((conv_igemm_kernel<3, MF, true, 2>), dim3(grid), dim3(256), lds, st, q);
-      else hipLaunchKernelGGL((conv_igemm_kernel<3, MF, true, 1>), dim3(grid), dim3(256), lds, st, q);
+      if (prof_mode() == 2) rf ? launch1<3, MF, true, 2, true>(q, grid, lds, st) : launch1<3, MF, true, 2, false>(q, grid, lds, st);
+      else rf ? launch1<3, MF, true, 1, true>(q, grid, lds, st) : launch1<3, MF, true, 1, false>(q, grid, lds, st);
       return 0;
     }
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<NPL, MF, SPLIT>), dim3(grid), dim3(256), lds, st, p);
+  if (rf) { launch1<NPL, MF, SPLIT, 0, true>(p, grid, lds, st); return 0; }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_v1_kernel<NPL, MF, SPLIT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / wgs_per_cu(MF));
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_v1_kernel<NPL, MF, SPLIT>), dim3(grid), dim3(256), lds, st, p);
   return 0;
 }
 
 int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t st) {
-  const int mf = plan(p, npl, ay, ax);
+  bool rf = false;
+  const int mf = choose(p, npl, ay, ax, rf);
   if (mf == 0) return 3;
   const int PIXPP = npl == 1 ? 64 : 32;
   p.npass = (p.region_px + PIXPP - 1) / PIXPP;
@@ -652,9 +1116,9 @@ int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t 
   { const char* e = getenv("BLADES_IGEMM_ABLATE"); p.ablate = e ? atoi(e) : 0; }
 #define GO(NPL, SPLIT)                                           \
   do {                                                           \
-    if (mf == 4) return launch<NPL, 4, SPLIT>(p, st);            \
-    if (mf == 2) return launch<NPL, 2, SPLIT>(p, st);            \
-    return launch<NPL, 1, SPLIT>(p, st);                         \
+    if (mf == 4) return launch<NPL, 4, SPLIT>(p, st, rf);        \
+    if (mf == 2) return launch<NPL, 2, SPLIT>(p, st, rf);        \
+    return launch<NPL, 1, SPLIT>(p, st, rf);                     \
   } while (0)
   if (npl == 3) GO(3, true);
   if (npl == 2) GO(2, true);
@@ -839,6 +1303,7 @@ BLADES_API int blades_conv_igemm_stats_nchunk(int N, int H, int W, int Ci, int H
   p.n_clients = n_clients; p.imgs_per_client = N / n_clients;
   int ay[MAXTAPS], ax[MAXTAPS];
   fill_forward(p, ay, ax, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad);
-  if (plan(p, npl, ay, ax) == 0) return 0;
+  bool rf = false;
+  if (choose(p, npl, ay, ax, rf) == 0) return 0;
   return stats_chunks(p, stats_B);
 }
