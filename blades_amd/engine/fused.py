@@ -151,6 +151,25 @@ class GradJoin:
         self.pending = None
 
 
+class BnBackHint:
+    """Link from a per-client BatchNorm's output to the convolution that consumes it.  When that convolution's
+    data-gradient kernel produces the *finished* gradient of the BatchNorm output (sole consumer, or the branch of a
+    GradJoin that adds onto the other), its epilogue also accumulates the BatchNorm's backward sums (sum g, sum g x
+    under the ReLU gate) and leaves them here; the BatchNorm backward then skips its reduction pass over the two
+    activation-sized tensors (profiles/r3_*serial_kernel_stats*: no pcbn_reduce<1> row)."""
+
+    __slots__ = ("x", "gate", "B", "pre", "dx")
+
+    def __init__(self, x, gate, B):
+        self.x, self.gate, self.B = x, gate, B
+        self.pre = None
+        self.dx = None
+
+
+def _bn_bwd_in_dgrad() -> bool:
+    return _os.environ.get("BLADES_BN_BWD_IN_DGRAD", "1") != "0"
+
+
 class _JoinTap(torch.autograd.Function):
     """Identity on the shortcut branch; its backward hands the branch's gradient to the block's GradJoin."""
 
@@ -173,6 +192,8 @@ class _PCConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mod, want_stats=False):
         ctx.join, mod.join = mod.join, None
+        ctx.sole, mod.sole = mod.sole, False
+        ctx.bn_hint = getattr(x, "_bn_hint", None) if _bn_bwd_in_dgrad() else None
         w = weight.to(x.dtype)
         b = mod.bias.to(x.dtype) if mod.bias is not None else None
         mod.bn_stats = None
@@ -256,9 +277,19 @@ class _PCConvFn(torch.autograd.Function):
                 if not (other.dtype == x.dtype and other.shape == x.shape
                         and other.is_contiguous(memory_format=torch.channels_last)):
                     other = other.to(x.dtype).contiguous(memory_format=torch.channels_last)
-            dx = _hipmod().conv_dgrad(gy, w, (int(x.shape[2]), int(x.shape[3])), int(mod.stride[0]),
-                                      int(mod.padding[0]), sink.npl, planes=mod.planes("dgrad"),
-                                      accumulate_into=other)
+            hint = ctx.bn_hint
+            # this kernel writes the finished gradient of x when x has no other consumer, or when it adds onto the
+            # other branch's tensor: then it can also do the first pass of the BatchNorm backward behind x
+            final = hint is not None and (other is not None or (join is None and ctx.sole))
+            if final and hint.x.shape == x.shape and Kc and x.shape[0] % Kc == 0:
+                dx, hint.pre = _hipmod().conv_dgrad(gy, w, (int(x.shape[2]), int(x.shape[3])), int(mod.stride[0]),
+                                                    int(mod.padding[0]), sink.npl, planes=mod.planes("dgrad"),
+                                                    accumulate_into=other, bn_bwd=(hint.x, hint.gate, hint.B))
+                hint.dx = dx
+            else:
+                dx = _hipmod().conv_dgrad(gy, w, (int(x.shape[2]), int(x.shape[3])), int(mod.stride[0]),
+                                          int(mod.padding[0]), sink.npl, planes=mod.planes("dgrad"),
+                                          accumulate_into=other)
             if join is not None and other is None:
                 join.pending, dx = dx, None  # first of the two branches: the other one adds onto this tensor
         elif ctx.needs_input_grad[0]:
@@ -299,10 +330,11 @@ class PCConv2d(nn.Module):
         self.sink = sink
         self.bn_stats = None  # (partial, nchunk) of the last forward(..., want_stats=True), consumed by the BN
         self.join = None      # GradJoin of the residual block whose input this convolution reads (set per forward)
+        self.sole = False     # this convolution is the only consumer of its input (set per forward)
         self._planes = {}     # "fwd" / "dgrad" / "stem": ops.conv_planes images of the shared weight, per round
 
-    def forward(self, x, want_stats: bool = False, join=None):
-        self.join = join
+    def forward(self, x, want_stats: bool = False, join=None, sole: bool = False):
+        self.join, self.sole = join, sole
         return _PCConvFn.apply(x, self.weight, self, want_stats)
 
     def prepare_planes(self):
@@ -552,6 +584,9 @@ class _PCBatchNormFn(torch.autograd.Function):
             gate = y if relu else None
         ctx.mod, ctx.relu, ctx.has_res, ctx.use_hip = mod, relu, res is not None, use_hip
         ctx.save_for_backward(x, gate, mean, invstd)
+        ctx.hint = None
+        if use_hip and _bn_bwd_in_dgrad() and x.dtype == torch.float32 and Kc:
+            ctx.hint = mod.last_hint = BnBackHint(x, gate, x.shape[0] // Kc)
         return y
 
     @staticmethod
@@ -570,8 +605,13 @@ class _PCBatchNormFn(torch.autograd.Function):
                 acc = id(mod.weight) in sink._written
                 sink._written.add(id(mod.weight))
                 sink._written.add(id(mod.bias))
+            pre, hint = None, ctx.hint
+            if hint is not None:
+                if hint.pre is not None and hint.dx is not None and hint.dx.data_ptr() == gy.data_ptr():
+                    pre = hint.pre
+                hint.pre = hint.dx = hint.x = hint.gate = None
             dx, gres = _hipmod().pcbn_backward(x, gy, y, sink.param(mod.weight), mean, invstd, Kc, sink.scale, U,
-                                               offg, offb, acc, want_gres)
+                                               offg, offb, acc, want_gres, pre_stats=pre)
         else:
             dx, gres, dgamma, dbeta = _bn_backward_ref(x, gy, y, mod.weight, mean, invstd, Kc, ctx.relu, want_gres)
             if mod.weight is not None:
@@ -857,14 +897,18 @@ class PCBatchNorm2d(nn.Module):
 
     def forward(self, x, residual=None, relu: bool = False, pre_stats=None):
         anchor = self.weight if self.weight is not None else x
-        return _PCBatchNormFn.apply(x, residual, anchor, self, relu, pre_stats)
+        self.last_hint = None
+        y = _PCBatchNormFn.apply(x, residual, anchor, self, relu, pre_stats)
+        if self.last_hint is not None:
+            y._bn_hint, self.last_hint = self.last_hint, None  # read by the convolution that consumes y
+        return y
 
 
-def _conv_bn(conv, bn, x, residual=None, relu: bool = False, join=None):
+def _conv_bn(conv, bn, x, residual=None, relu: bool = False, join=None, sole: bool = False):
     """``bn(conv(x))`` with the BatchNorm statistics taken from the convolution kernel's epilogue when both are
     the engine's own modules (no separate statistics pass over the convolution output)."""
     if isinstance(conv, PCConv2d) and isinstance(bn, PCBatchNorm2d):
-        y = conv(x, want_stats=True, join=join)
+        y = conv(x, want_stats=True, join=join, sole=sole)
         pre, conv.bn_stats = conv.bn_stats, None
         return bn(y, residual=residual, relu=relu, pre_stats=pre)
     return bn(conv(x), residual=residual, relu=relu)
@@ -895,10 +939,11 @@ class PCResBlock(nn.Module):
             # (after conv1: the tap's backward node is then the younger one and runs first, so the convolution's
             # data-gradient kernel is the branch that does the adding)
             sc = _JoinTap.apply(x, join) if join is not None else x
+        # (`out` has no consumer but the next convolution: its data-gradient kernel does the BatchNorm backward sums)
         if self.bottleneck:
-            out = _conv_bn(b.conv2, b.bn2, out, relu=True)
-            return _conv_bn(b.conv3, b.bn3, out, residual=sc, relu=True)
-        return _conv_bn(b.conv2, b.bn2, out, residual=sc, relu=True)
+            out = _conv_bn(b.conv2, b.bn2, out, relu=True, sole=True)
+            return _conv_bn(b.conv3, b.bn3, out, residual=sc, relu=True, sole=True)
+        return _conv_bn(b.conv2, b.bn2, out, residual=sc, relu=True, sole=True)
 
 
 class PCResNet(nn.Module):

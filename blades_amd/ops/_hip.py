@@ -68,6 +68,10 @@ _pcbn_bwd = _sig("blades_pcbn_backward", [_P, _P, _P, _P, _P, _P, c_int, c_int, 
                                           c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P], c_int)
 
 
+_pcbn_bwd2 = _opt_sig("blades_pcbn_backward2", [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_long, c_long,
+                                                 c_long, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P], c_int)
+
+
 def _affine(t, Kc: int, C: int, device, name: str):
     """Affine vector of a per-client normalisation: [C] shared by all clients (stride 0) or [Kc, C] per client."""
     if t is None:
@@ -519,8 +523,10 @@ def pcbn_forward(x, res, gamma, beta, Kc: int, eps: float, relu: bool, want_mask
 
 
 def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block, off_gamma: int, off_beta: int,
-                  accumulate: bool, want_gres: bool):
-    """``relu_mask``: the uint8 bitmask returned by ``pcbn_forward(..., want_mask=True)`` (``None`` = no ReLU)."""
+                  accumulate: bool, want_gres: bool, pre_stats=None):
+    """``relu_mask``: the uint8 bitmask returned by ``pcbn_forward(..., want_mask=True)`` (``None`` = no ReLU).
+    ``pre_stats = (partial, nchunk)``: the raw backward sums of ``gy`` written by the data-gradient kernel that
+    produced it (``conv_dgrad(bn_bwd=...)``): the reduction pass over ``gy`` and ``x`` is skipped."""
     if x.dtype not in _ACT_DTYPES:
         raise ValueError(f"pcbn_backward: unsupported dtype {x.dtype}")
     _chk_nhwc_bf16(x, "x", x.dtype)
@@ -543,14 +549,25 @@ def pcbn_backward(x, gy, relu_mask, gamma, mean, invstd, Kc: int, coef, U_block,
         coef = _vec(coef, Kc, dev, name="coef")
     if mean.numel() != Kc * C or invstd.numel() != Kc * C:
         raise ValueError("pcbn_backward: stats shape mismatch")
-    nch = _pcbn_nchunk(P, C, x.element_size())
-    partial = _empty(Kc * nch * C * 2, device=dev)
+    pre_nch = 0
+    if pre_stats is not None and _pcbn_bwd2 is not None and x.dtype == torch.float32:
+        partial, pre_nch = pre_stats
+        if partial.numel() != Kc * pre_nch * C * 2:
+            raise ValueError("pcbn_backward: pre_stats does not match (Kc, nchunk, C)")
+    else:
+        nch = _pcbn_nchunk(P, C, x.element_size())
+        partial = _empty(Kc * nch * C * 2, device=dev)
     k = _empty(3, Kc, C, device=dev)
     dx = _empty_like(x)
     gres = _empty_like(x) if want_gres else None
-    rc = _pcbn_bwd(_ptr(x), _ptr(gy), _ptr(relu_mask), _ptr(gamma), _ptr(mean), _ptr(invstd), Kc, P, C, _ptr(coef),
-                   _ptr(U_block), ld, off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(k[0]), _ptr(k[1]),
-                   _ptr(k[2]), _ptr(dx), _ptr(gres), x.element_size(), gstride, _stream())
+    if _pcbn_bwd2 is not None:
+        rc = _pcbn_bwd2(_ptr(x), _ptr(gy), _ptr(relu_mask), _ptr(gamma), _ptr(mean), _ptr(invstd), Kc, P, C, _ptr(coef),
+                        _ptr(U_block), ld, off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(k[0]), _ptr(k[1]),
+                        _ptr(k[2]), _ptr(dx), _ptr(gres), x.element_size(), gstride, int(pre_nch), _stream())
+    else:
+        rc = _pcbn_bwd(_ptr(x), _ptr(gy), _ptr(relu_mask), _ptr(gamma), _ptr(mean), _ptr(invstd), Kc, P, C, _ptr(coef),
+                       _ptr(U_block), ld, off_gamma, off_beta, int(accumulate), _ptr(partial), _ptr(k[0]), _ptr(k[1]),
+                       _ptr(k[2]), _ptr(dx), _ptr(gres), x.element_size(), gstride, _stream())
     if rc != 0:
         raise ValueError("pcbn_backward: unsupported shape")
     return dx, gres
@@ -1004,6 +1021,9 @@ def conv_igemm_supported(x: torch.Tensor, weight: torch.Tensor, stride, pad, dil
 
 _conv_igemm2 = _opt_sig("blades_conv_igemm2", [_P, _P, _P, _P, _P] + [c_int] * 14 + [c_long, c_long, _P, c_int, c_int, _P],
                         c_int)
+_conv_igemm3 = _opt_sig("blades_conv_igemm3", [_P, _P, _P, _P, _P] + [c_int] * 14 + [c_long, c_long, _P, c_int, c_int, _P, _P, _P],
+                        c_int)
+_conv_dgrad_stats_nchunk = _opt_sig("blades_conv_dgrad_stats_nchunk", [c_int] * 14, c_int)
 _conv_wprep = _opt_sig("blades_conv_wprep", [_P, _P] + [c_int] * 7 + [c_long, _P], c_int)
 
 
@@ -1028,7 +1048,7 @@ def conv_planes(weight, mode: int, npl: int, out=None):
 
 
 def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, mode, npl, stats_B=0, planes=None,
-               accumulate=False):
+               accumulate=False, bn_bwd=None):
     """``weight``: [Co, Ci, kh, kw] shared by every image, or [Kc, Co, Ci, kh, kw] — one weight set per client
     (clients may be rows of a wider matrix: any stride along dim 0, contiguous inside a client).  ``planes``: the
     ``conv_planes`` image of a shared weight (the weight itself is then not read)."""
@@ -1068,6 +1088,18 @@ def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, 
         nch = _conv_igemm_stats_nchunk(N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, npl, nc, int(stats_B))
         if nch > 0:
             partial = _empty((N // int(stats_B)) * nch * Co * 2, device=inp.device)
+    if bn_bwd is not None and mode == 1 and npl > 1 and _conv_igemm3 is not None:
+        # first pass of the BatchNorm backward that consumes this data gradient, from the kernel's epilogue
+        bx, bmask, bB = bn_bwd
+        nch = _conv_dgrad_stats_nchunk(N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, npl, nc, int(bB))
+        if nch > 0:
+            partial = _empty((N // int(bB)) * nch * Ci * 2, device=inp.device)
+            rc = _conv_igemm3(_ptr(inp), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, H, W, Ci, Ho, Wo, Co, kh, kw,
+                              stride, pad, mode, npl, nc, wstride, bstride, _ptr(partial), int(bB), flags, _ptr(bx),
+                              _ptr(bmask), _stream())
+            if rc != 0:
+                raise ValueError(f"conv_igemm: data gradient with BatchNorm sums rejected (rc={rc})")
+            return partial, nch
     if _conv_igemm2 is not None:
         rc = _conv_igemm2(_ptr(inp), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), N, H, W, Ci, Ho, Wo, Co, kh, kw, stride,
                           pad, mode, npl, nc, wstride, bstride, _ptr(partial),
@@ -1164,10 +1196,16 @@ def conv_forward(x, weight, bias, stride: int, pad: int, npl: int, stats_B: int 
     return (y, pre) if stats_B else y
 
 
-def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int, planes=None, accumulate_into=None):
+def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int, planes=None, accumulate_into=None, bn_bwd=None):
     """dx of conv2d(x, weight) given gy (channels-last); ``in_hw`` = (H, W) of x.  ``accumulate_into``: a tensor of
     dx's shape and layout that the result is added to in the kernel's epilogue (and that is returned) — the other
-    gradient branch of a residual block, so no separate elementwise add runs over the tensor."""
+    gradient branch of a residual block, so no separate elementwise add runs over the tensor.
+
+    ``bn_bwd = (x_bn, relu_mask, B)``: dx is the gradient of the output of a per-client BatchNorm (input ``x_bn``, same
+    shape as dx; gate bitmask of ``pcbn_forward`` or None; B images per client).  The kernel's epilogue then also writes
+    that BatchNorm's backward sums and the call returns ``(dx, pre)`` with ``pre`` = the argument for
+    ``pcbn_backward(pre_stats=...)`` — or None where the geometry does not allow it (the caller's BatchNorm then
+    runs its own reduction pass)."""
     dt = torch.bfloat16 if npl == 1 else torch.float32
     _chk_nhwc(gy, "gy", dt)
     N, Co, Ho, Wo = gy.shape
@@ -1184,6 +1222,19 @@ def conv_dgrad(gy, weight, in_hw, stride: int, pad: int, npl: int, planes=None, 
         dx = _empty((N, Ci, H, W), dtype=dt, device=gy.device, memory_format=torch.channels_last)
         if Ci == 1 or H * W == 1:
             dx = dx.as_strided(dx.shape, (H * W * Ci, 1, W * Ci, Ci))
+    if bn_bwd is not None:
+        bx, bmask, bB = bn_bwd
+        ok = (npl > 1 and bx.dtype == torch.float32 and tuple(bx.shape) == tuple(dx.shape) and bx.stride() == dx.stride()
+              and Ci % 8 == 0 and N % int(bB) == 0
+              and (bmask is None or (bmask.dtype == torch.uint8 and bmask.is_contiguous() and bmask.numel() * 8 == bx.numel())))
+        pre = None
+        if ok:
+            pre = _conv_call(gy, weight, None, dx, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 1, npl, planes=planes,
+                             accumulate=accumulate_into is not None, bn_bwd=(bx, bmask, int(bB)))
+        else:
+            _conv_call(gy, weight, None, dx, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 1, npl, planes=planes,
+                       accumulate=accumulate_into is not None)
+        return dx, pre
     _conv_call(gy, weight, None, dx, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, 1, npl, planes=planes,
                accumulate=accumulate_into is not None)
     return dx

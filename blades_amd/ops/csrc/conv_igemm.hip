@@ -92,6 +92,14 @@ struct IgemmParams {
   long seg_goff[MAXSEG];
   int accumulate;             // out += result (the data gradient of a residual block's first convolution lands on the
                               // shortcut branch's gradient: no separate elementwise add over the tensor)
+  // data gradient, fp32 tensors: first pass of the BatchNorm backward that consumes this gradient (the layer that
+  // produced this convolution's input).  bstat_x = that BatchNorm's input (same shape/layout as `out`), bstat_mask =
+  // its ReLU gate bitmask (or null); stats then receives per (client, chunk, channel) the raw sums
+  // (sum g, sum g * x), g = the finished gradient (after `accumulate`) gated by the mask — pcbn.hip's finalize turns
+  // them into (dbeta, dgamma).  stats_chunk0 = first chunk of this launch (strided layers: one launch per class).
+  const float* bstat_x;
+  const unsigned char* bstat_mask;
+  int stats_chunk0, stats_class, stats_classes;
   int Hphys, Wphys, in_rm, in_cm;  // the input may be a strided view in[:, ::rm, ::cm] of a [Hphys][Wphys] image (a
                                    // strided 1x1 convolution only ever touches those pixels: it runs as a stride-1
                                    // convolution on the view, staging a quarter of the pixels)
@@ -363,6 +371,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_v1_kernel(cons
   // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
   const bool vec_out = (p.Co % 4) == 0;
   const bool want_stats = SPLIT && p.stats != nullptr;  // block-uniform
+  const bool bstat = want_stats && p.bstat_x != nullptr;  // BatchNorm-backward sums instead of the forward ones
   f32x4 st_s[4], st_q[4];
 #pragma unroll
   for (int cf = 0; cf < 4; ++cf) { st_s[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; st_q[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -378,12 +387,22 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_v1_kernel(cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? bias_c[co + j] : 0.f;
       }
-      if (want_stats) { st_s[cf] += v; st_q[cf] += v * v; }
+      if (want_stats && !bstat) { st_s[cf] += v; st_q[cf] += v * v; }
       if constexpr (SPLIT) {
         float* dst = reinterpret_cast<float*>(p.out) + out_pix[pf] * p.Co + co;
         if (vec_out) {
           if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
           *reinterpret_cast<f32x4*>(dst) = v;
+          if (bstat) {  // (Co % 8 == 0 is checked on the host)
+            const size_t off = (size_t)out_pix[pf] * p.Co + co;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.bstat_x + off);
+            const unsigned mb = p.bstat_mask != nullptr ? (unsigned)p.bstat_mask[off >> 3] >> (co & 4) : 0xFu;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float g = (mb >> j) & 1u ? v[j] : 0.f;
+              st_s[cf][j] += g; st_q[cf][j] += g * xv[j];
+            }
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
@@ -437,7 +456,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_v1_kernel(cons
           for (int w = 0; w < 4; ++w) a += red[(w * 64 + ch) * 2 + which];
           const int cl = img0 / p.stats_B, in_cl = img0 - cl * p.stats_B;
           const int chunk = p.TI == 1 ? in_cl * p.tiles_per_img + (mt - img0 * p.tiles_per_img) : in_cl / p.TI;
-          p.stats[(((size_t)cl * p.stats_nchunk + chunk) * p.Co + n0 + ch) * 2 + which] = a;
+          p.stats[(((size_t)cl * p.stats_nchunk + p.stats_chunk0 + chunk) * p.Co + n0 + ch) * 2 + which] = a;
         }
       }
     }
@@ -798,6 +817,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   // ---- epilogue: lane = (pixel li of fragment pf, channels cf*16 + kg*4 .. +3) -------------------------------
   const bool vec_out = (p.Co % 4) == 0;
   const bool want_stats = SPLIT && p.stats != nullptr;  // block-uniform
+  const bool bstat = want_stats && p.bstat_x != nullptr;  // BatchNorm-backward sums instead of the forward ones
   f32x4 st_s[NCF], st_q[NCF];
 #pragma unroll
   for (int cf = 0; cf < NCF; ++cf) { st_s[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; st_q[cf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -815,12 +835,22 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += co + j < p.Co ? bias_c[co + j] : 0.f;
       }
-      if (want_stats) { st_s[cf] += v; st_q[cf] += v * v; }
+      if (want_stats && !bstat) { st_s[cf] += v; st_q[cf] += v * v; }
       if constexpr (SPLIT) {
         float* dst = reinterpret_cast<float*>(p.out) + out_pix_pf * p.Co + co;
         if (vec_out) {
           if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
           *reinterpret_cast<f32x4*>(dst) = v;
+          if (bstat) {  // (Co % 8 == 0 is checked on the host)
+            const size_t off = (size_t)out_pix_pf * p.Co + co;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.bstat_x + off);
+            const unsigned mb = p.bstat_mask != nullptr ? (unsigned)p.bstat_mask[off >> 3] >> (co & 4) : 0xFu;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float g = (mb >> j) & 1u ? v[j] : 0.f;
+              st_s[cf][j] += g; st_q[cf][j] += g * xv[j];
+            }
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (co + j < p.Co) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
@@ -875,7 +905,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
           for (int w = 0; w < (RF ? 2 : 4); ++w) a += red[(w * 64 + ch) * 2 + which];
           const int cl = img0 / p.stats_B, in_cl = img0 - cl * p.stats_B;
           const int chunk = p.TI == 1 ? in_cl * p.tiles_per_img + (mt - img0 * p.tiles_per_img) : in_cl / p.TI;
-          p.stats[(((size_t)cl * p.stats_nchunk + chunk) * p.Co + n0 + ch) * 2 + which] = a;
+          p.stats[(((size_t)cl * p.stats_nchunk + p.stats_chunk0 + chunk) * p.Co + n0 + ch) * 2 + which] = a;
         }
       }
     }
@@ -1109,8 +1139,11 @@ int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t 
   for (int t = 0; t < p.ntaps; ++t) p.tap_off[t] = (ay[t] - p.aymin) * p.WS + ax[t];
   p.n_ntiles = p.Cop / BN;
   if (p.stats != nullptr) {
-    p.stats_nchunk = stats_chunks(p, p.stats_B);
-    if (p.stats_nchunk == 0 || npl == 1) return 6;
+    const int per = stats_chunks(p, p.stats_B);
+    if (per == 0 || npl == 1) return 6;
+    const int classes = p.stats_classes > 0 ? p.stats_classes : 1;
+    p.stats_nchunk = per * classes;
+    p.stats_chunk0 = p.stats_class * per;
   }
   if (p.nseg == 0) { p.nseg = 1; p.seg_begin[0] = 0; p.seg_begin[1] = p.ntaps; p.seg_goff[0] = 0; }
   { const char* e = getenv("BLADES_IGEMM_ABLATE"); p.ablate = e ? atoi(e) : 0; }
@@ -1207,10 +1240,14 @@ BLADES_API int blades_conv_wprep(const float* w, void* ws, int Co, int Ci, int k
 // [N / stats_B clients][blades_conv_igemm_stats_nchunk(...) chunks][Co][2] floats.
 // flags: 1 = `ws` already holds this layer's planes (blades_conv_wprep; `w` is not read); 2 = out += result.
 // returns 0 ok; nonzero = unsupported (caller falls back)
-BLADES_API int blades_conv_igemm2(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
+// bstat_x / bstat_mask (mode 1, fp32 tensors, stats != null): instead of the forward sums, `stats` receives the raw
+// BatchNorm-backward sums of the finished data gradient against bstat_x (see IgemmParams), in
+// blades_conv_dgrad_stats_nchunk(...) chunks per client.
+BLADES_API int blades_conv_igemm3(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
                                   int W, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad, int mode,
                                   int npl, int n_clients, long w_client_stride, long bias_client_stride,
-                                  float* stats, int stats_B, int flags, hipStream_t st) {
+                                  float* stats, int stats_B, int flags, const float* bstat_x,
+                                  const unsigned char* bstat_mask, hipStream_t st) {
   if (npl < 1 || npl > 3 || kh * kw > MAXTAPS || stride < 1 || N <= 0) return 1;
   if (n_clients < 1) n_clients = 1;
   if (N % n_clients || n_clients > 65535) return 5;
@@ -1236,7 +1273,14 @@ BLADES_API int blades_conv_igemm2(const void* in, const float* w, const float* b
     fill_forward(p, ay, ax, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad);
     return dispatch(p, npl, ay, ax, st);
   }
-  if (stats != nullptr) return 6;
+  if (stats != nullptr) {
+    if (bstat_x == nullptr || npl == 1 || Ci % 8 != 0) return 6;
+    // every output parity class must be one launch of the same size (the chunk ranges of the classes are laid side
+    // by side), and must have a tap (a class without one is skipped in accumulate mode)
+    if (H % stride != 0 || W % stride != 0 || kh < stride || kw < stride) return 6;
+    p.stats = stats; p.stats_B = stats_B; p.bstat_x = bstat_x; p.bstat_mask = bstat_mask;
+    p.stats_classes = stride * stride;
+  }
   p.Hi = Ho; p.Wi = Wo; p.Ci = Co; p.Hout = H; p.Wout = W; p.Co = Ci;
   p.Hphys = Ho; p.Wphys = Wo;
   p.so = stride; p.si = 1;
@@ -1245,6 +1289,7 @@ BLADES_API int blades_conv_igemm2(const void* in, const float* w, const float* b
       if (ph >= H || pw >= W) continue;
       IgemmParams q = p;
       q.poy = ph; q.pox = pw;
+      q.stats_class = ph * stride + pw;
       q.Hs = (H - ph + stride - 1) / stride; q.Ws = (W - pw + stride - 1) / stride;
       int n = 0;
       for (int r = 0; r < kh; ++r) {
@@ -1282,6 +1327,14 @@ BLADES_API int blades_conv_igemm_prof(unsigned long long* host) {
   return 0;
 }
 
+BLADES_API int blades_conv_igemm2(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
+                                  int W, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad, int mode,
+                                  int npl, int n_clients, long w_client_stride, long bias_client_stride,
+                                  float* stats, int stats_B, int flags, hipStream_t st) {
+  return blades_conv_igemm3(in, w, bias, out, ws, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, pad, mode, npl, n_clients,
+                            w_client_stride, bias_client_stride, stats, stats_B, flags, nullptr, nullptr, st);
+}
+
 BLADES_API int blades_conv_igemm(const void* in, const float* w, const float* bias, void* out, void* ws, int N, int H,
                                  int W, int Ci, int Ho, int Wo, int Co, int kh, int kw, int stride, int pad, int mode,
                                  int npl, int n_clients, long w_client_stride, long bias_client_stride,
@@ -1306,4 +1359,44 @@ BLADES_API int blades_conv_igemm_stats_nchunk(int N, int H, int W, int Ci, int H
   bool rf = false;
   if (choose(p, npl, ay, ax, rf) == 0) return 0;
   return stats_chunks(p, stats_B);
+}
+
+// Chunks per client of the BatchNorm-backward sums a data-gradient call with bstat_x writes; 0 = not available.
+BLADES_API int blades_conv_dgrad_stats_nchunk(int N, int H, int W, int Ci, int Ho, int Wo, int Co, int kh, int kw,
+                                              int stride, int pad, int npl, int n_clients, int stats_B) {
+  if (npl < 2 || npl > 3 || kh * kw > MAXTAPS || stride < 1 || N <= 0 || stats_B <= 0 || Ci % 8 != 0) return 0;
+  if (H % stride != 0 || W % stride != 0 || kh < stride || kw < stride) return 0;
+  if (n_clients < 1) n_clients = 1;
+  if (N % n_clients) return 0;
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.N = N; p.ntw = kh * kw; p.Cop = round_up(Ci, BN); p.Cip = round_up(Co, KC);
+  p.n_clients = n_clients; p.imgs_per_client = N / n_clients;
+  p.in_rm = p.in_cm = 1;
+  p.Hi = Ho; p.Wi = Wo; p.Ci = Co; p.Hout = H; p.Wout = W; p.Co = Ci;
+  p.Hphys = Ho; p.Wphys = Wo; p.so = stride; p.si = 1;
+  int per = -1;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      IgemmParams q = p;
+      int ay[MAXTAPS], ax[MAXTAPS];
+      q.poy = ph; q.pox = pw;
+      q.Hs = (H - ph + stride - 1) / stride; q.Ws = (W - pw + stride - 1) / stride;
+      int n = 0;
+      for (int r = 0; r < kh; ++r) {
+        if ((ph + pad - r) % stride != 0) continue;
+        for (int s = 0; s < kw; ++s) {
+          if ((pw + pad - s) % stride != 0) continue;
+          ay[n] = (ph + pad - r) / stride; ax[n] = (pw + pad - s) / stride; ++n;
+        }
+      }
+      q.ntaps = n;
+      if (n == 0) return 0;
+      bool rf = false;
+      if (choose(q, npl, ay, ax, rf) == 0) return 0;
+      const int c = stats_chunks(q, stats_B);
+      if (c == 0 || (per >= 0 && c != per)) return 0;
+      per = c;
+    }
+  return per * stride * stride;
 }

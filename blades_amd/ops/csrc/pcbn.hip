@@ -184,7 +184,8 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_kernel(const float* __r
                                                                 long off_beta, int accumulate,
                                                                 float* __restrict__ k_scale,  // gamma*invstd
                                                                 float* __restrict__ k_b,      // dbeta/m
-                                                                float* __restrict__ k_c) {    // dgamma/m
+                                                                float* __restrict__ k_c,      // dgamma/m
+                                                                int raw) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i >= Kc * C) return;
   const int c = i / C, ch = i % C;
@@ -193,6 +194,9 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_kernel(const float* __r
     const float* q = partial + ((size_t)(c * nchunk + k) * C + ch) * 2;
     sg += (double)q[0]; sgx += (double)q[1];
   }
+  // raw: the partials are (sum g, sum g * x) from the epilogue of the convolution that produced the gradient
+  // (conv_igemm.hip, bstat_x): sum g * xhat = invstd * (sum g x - mean * sum g), in double
+  if (raw) sgx = (double)invstd[i] * (sgx - (double)mean[i] * sg);
   const float g = gamma ? gamma[(size_t)c * gstride + ch] : 1.f;
   if (U != nullptr) {
     float* row = U + (size_t)c * ld;
@@ -275,12 +279,15 @@ template <typename T>
 int pcbn_backward_t(const void* x, const void* gy, const void* relu_mask, const float* gamma, int gstride, const float* mean,
                     const float* invstd, int Kc, int P, int C, const float* coef, float* U, long ld, long off_gamma,
                     long off_beta, int accumulate, float* partial, float* k_scale, float* k_b, float* k_c, void* dx,
-                    void* gres, hipStream_t st) {
-  const int ppc = chunk_pixels(C, sizeof(T)), nch = cdiv(P, ppc);
-  hipLaunchKernelGGL((pcbn_reduce_kernel<1, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
-                     (const T*)gy, (const unsigned char*)relu_mask, mean, invstd, P, C, ppc, nch, partial);
+                    void* gres, int pre_nchunk, hipStream_t st) {
+  // pre_nchunk > 0: `partial` already holds the raw sums, written by the data-gradient kernel that produced gy
+  const int ppc = chunk_pixels(C, sizeof(T)), nch = pre_nchunk > 0 ? pre_nchunk : cdiv(P, ppc);
+  if (pre_nchunk <= 0)
+    hipLaunchKernelGGL((pcbn_reduce_kernel<1, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
+                       (const T*)gy, (const unsigned char*)relu_mask, mean, invstd, P, C, ppc, nch, partial);
   hipLaunchKernelGGL(pcbn_bwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
-                     gamma, gstride, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c);
+                     gamma, gstride, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c,
+                     pre_nchunk > 0 ? 1 : 0);
   int gx = cdiv((long)P * (C / 8), TPB);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL((pcbn_bwd_apply_kernel<T>), dim3(gx, Kc), dim3(TPB), 0, st, (const T*)x, (const T*)gy,
@@ -310,17 +317,26 @@ BLADES_API int blades_pcbn_forward(const void* x, const void* res, const float* 
 
 // workspace: partial (as forward), k_scale/k_b/k_c: Kc*C floats each.
 // relu_mask: the bitmask written by the forward pass (Kc*P*C/8 bytes), or nullptr when there was no ReLU.
+BLADES_API int blades_pcbn_backward2(const void* x, const void* gy, const void* relu_mask, const float* gamma,
+                                     const float* mean, const float* invstd, int Kc, int P, int C, const float* coef,
+                                     float* U, long ld, long off_gamma, long off_beta, int accumulate, float* partial,
+                                     float* k_scale, float* k_b, float* k_c, void* dx, void* gres, int esize,
+                                     int gstride, int pre_nchunk, hipStream_t st) {
+  if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
+  if (esize == 4)
+    return pcbn_backward_t<float>(x, gy, relu_mask, gamma, gstride, mean, invstd, Kc, P, C, coef, U, ld, off_gamma, off_beta,
+                                  accumulate, partial, k_scale, k_b, k_c, dx, gres, pre_nchunk, st);
+  if (esize == 2 && pre_nchunk <= 0)
+    return pcbn_backward_t<unsigned short>(x, gy, relu_mask, gamma, gstride, mean, invstd, Kc, P, C, coef, U, ld, off_gamma,
+                                           off_beta, accumulate, partial, k_scale, k_b, k_c, dx, gres, 0, st);
+  return 2;
+}
+
 BLADES_API int blades_pcbn_backward(const void* x, const void* gy, const void* relu_mask, const float* gamma,
                                     const float* mean, const float* invstd, int Kc, int P, int C, const float* coef,
                                     float* U, long ld, long off_gamma, long off_beta, int accumulate, float* partial,
                                     float* k_scale, float* k_b, float* k_c, void* dx, void* gres, int esize,
                                     int gstride, hipStream_t st) {
-  if (C % 8 != 0 || C > 2048 || (TPB % (C / 8)) != 0 || Kc <= 0 || P <= 0) return 1;
-  if (esize == 4)
-    return pcbn_backward_t<float>(x, gy, relu_mask, gamma, gstride, mean, invstd, Kc, P, C, coef, U, ld, off_gamma, off_beta,
-                                  accumulate, partial, k_scale, k_b, k_c, dx, gres, st);
-  if (esize == 2)
-    return pcbn_backward_t<unsigned short>(x, gy, relu_mask, gamma, gstride, mean, invstd, Kc, P, C, coef, U, ld, off_gamma,
-                                           off_beta, accumulate, partial, k_scale, k_b, k_c, dx, gres, st);
-  return 2;
+  return blades_pcbn_backward2(x, gy, relu_mask, gamma, mean, invstd, Kc, P, C, coef, U, ld, off_gamma, off_beta,
+                               accumulate, partial, k_scale, k_b, k_c, dx, gres, esize, gstride, 0, st);
 }

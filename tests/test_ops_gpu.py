@@ -1231,6 +1231,70 @@ def test_conv_epilogue_batchnorm_statistics(dev, Kc, B, Ci, HW, Co, k, s, p):
             torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("Kc,B,Ci,HW,Co,k,s,p,acc,gate", [
+    (3, 8, 64, 32, 64, 3, 1, 1, False, True),    # one image per tile
+    (2, 8, 64, 32, 128, 3, 2, 1, True, True),    # strided: one launch per output parity class, adding onto the shortcut
+    (3, 8, 128, 16, 128, 3, 1, 1, True, True),
+    (2, 16, 256, 8, 256, 3, 1, 1, False, False),  # four images per tile, BatchNorm without ReLU
+    (2, 16, 512, 4, 512, 3, 1, 1, True, True),   # sixteen images per tile (register-fed weight path)
+    (2, 8, 128, 16, 256, 3, 2, 1, False, True),
+])
+def test_conv_dgrad_epilogue_batchnorm_backward_sums(dev, Kc, B, Ci, HW, Co, k, s, p, acc, gate):
+    """The data-gradient kernel's epilogue does the first pass of the BatchNorm backward behind its output
+    (VERDICT r2 item 2): per (client, chunk, channel) the sums of g and g * x under the ReLU gate, g = the finished
+    gradient.  They must equal an fp64 reduction of the stored gradient, and pcbn_backward fed with them must give
+    what it computes with its own reduction pass (reference: BatchNorm2d backward over one client's batch)."""
+    from blades_amd.ops import _hip as h
+
+    torch.manual_seed(2)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    Ho = (HW + 2 * p - k) // s + 1
+    gy = cl(torch.randn(Kc * B, Co, Ho, Ho, device=dev))
+    w = torch.randn(Co, Ci, k, k, device=dev) / (Co * k * k) ** 0.5
+    xbn = cl(torch.randn(Kc * B, Ci, HW, HW, device=dev) * 1.5 + 0.7)     # the BatchNorm's input (a conv output)
+    gamma, beta = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev)
+    _, mean, invstd, mask = h.pcbn_forward(xbn, None, gamma, beta, Kc, 1e-5, gate, want_mask=True)
+    other = cl(torch.randn(Kc * B, Ci, HW, HW, device=dev)) if acc else None
+    ref = h.conv_dgrad(gy, w, (HW, HW), s, p, 3, accumulate_into=other.clone() if acc else None)
+    dx, pre = h.conv_dgrad(gy, w, (HW, HW), s, p, 3, accumulate_into=other.clone() if acc else None,
+                           bn_bwd=(xbn, mask if gate else None, B))
+    assert torch.equal(dx, ref)
+    assert pre is not None
+    partial, nch = pre
+    got = partial.view(Kc, nch, Ci, 2).double().sum(dim=1)
+    g = dx.permute(0, 2, 3, 1).reshape(Kc, -1, Ci).double()
+    xc = xbn.permute(0, 2, 3, 1).reshape(Kc, -1, Ci).double()
+    if gate:
+        y = (xc - mean.view(Kc, 1, Ci).double()) * invstd.view(Kc, 1, Ci).double() * gamma.double() + beta.double()
+        bits = mask.view(Kc, -1, Ci // 8)
+        m = torch.stack([(bits >> j) & 1 for j in range(8)], dim=-1).reshape(Kc, -1, Ci).double()
+        assert float(((y > 0).double() - m).abs().mean()) < 1e-4  # the mask is the forward gate
+        g = g * m
+    torch.testing.assert_close(got[..., 0], g.sum(dim=1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(got[..., 1], (g * xc).sum(dim=1), rtol=1e-5, atol=2e-3)
+    coef = torch.ones(Kc, device=dev)
+    outs = []
+    for ps in (None, pre):
+        U = torch.zeros(Kc, 2 * Ci, device=dev)
+        ddx, gres = h.pcbn_backward(xbn, dx, mask if gate else None, gamma, mean, invstd, Kc, coef, U, 0, Ci, False, gate,
+                                    pre_stats=ps)
+        outs.append((ddx, U))
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-5, atol=2e-5)
+
+
+def test_conv_dgrad_batchnorm_sums_declined_for_pointwise_strided(dev):
+    """A strided 1x1 convolution reaches one output parity class only: no sums are offered, the caller reduces itself."""
+    from blades_amd.ops import _hip as h
+
+    gy = torch.randn(16, 128, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(128, 64, 1, 1, device=dev)
+    xbn = torch.randn(16, 64, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    dx, pre = h.conv_dgrad(gy, w, (32, 32), 2, 0, 3, bn_bwd=(xbn, None, 8))
+    assert pre is None
+    assert torch.equal(dx, h.conv_dgrad(gy, w, (32, 32), 2, 0, 3))
+
+
 def test_conv_epilogue_statistics_decline_straddling_tiles(dev):
     """Three images per client, sixteen per tile: a tile would mix clients, so no statistics are offered."""
     from blades_amd.ops import _hip as h
