@@ -17,8 +17,9 @@ makes ``supports()`` return False and the engine falls back to the generic
 vectorised path.
 
 Samples are ordered client-major (index = ``c*B + b``); 4-D activations are
-channels-last, bf16 (or the engine's amp dtype); reductions and the per-client
-gradients are fp32.
+channels-last, fp32 by default (the kernels split them exactly into bf16 planes
+for the matrix cores) or bf16 in the ``bf16`` compute mode; reductions and the
+per-client gradients are fp32.
 """
 import copy
 import os as _os
@@ -198,8 +199,8 @@ class _PCConvFn(torch.autograd.Function):
         b = mod.bias.to(x.dtype) if mod.bias is not None else None
         mod.bn_stats = None
         if x.is_cuda and x.dim() == 4:
-            # keep the whole network in NHWC: MIOpen's bf16 kernels are NHWC (an NCHW input is transposed
-            # around every call) and so are the per-client BN / wgrad kernels.  A one-channel image is
+            # keep the whole network in NHWC: the engine's convolution, per-client BN and weight-gradient kernels are
+            # channels-last (and so are the library's bf16 kernels of the fallback path).  A one-channel image is
             # "contiguous" in both layouts and PyTorch then assumes NCHW — say NHWC through the strides.
             if x.shape[1] == 1 and x.is_contiguous():
                 x = x.as_strided(x.shape, (x.stride(0), 1, x.stride(2), x.stride(3)))

@@ -98,10 +98,8 @@ class ClientEngine:
         self.timers: Dict[str, float] = {}
         self.round = 0
         if self.device.type == "cuda":
-            # MIOpen "find" mode: without it the immediate-mode fallback picks the naive
-            # direct-convolution kernels for these shapes (60-80 ms per conv, see
-            # profiles/r1_v0_vmap_engine_kernel_stats.csv); with it the NHWC bf16 implicit-GEMM
-            # MFMA kernels are selected.  Shapes are static, so the search cost is paid once.
+            # Only the library fallbacks use this (BLADES_CONV_IMPL=miopen, the grouped/vmap path of models the fused
+            # executor does not cover): the default training paths run the engine's own convolution kernels.
             torch.backends.cudnn.benchmark = True
 
         # ---- parameter layout (named_parameters order == reference flattening)
