@@ -28,19 +28,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
+// Workgroup -> (tile pair, column split).  The grid is linear; hardware deals consecutive workgroups round-robin over
+// the 8 XCDs, so workgroup b is given work item (b % 8) * per_xcd + b / 8: an XCD receives a contiguous range of
+// (split, pair) items, i.e. all tile pairs of the same column split run on one XCD at the same time and the eight to
+// nine workgroups that read the same 128 rows share them through that XCD's L2 (pair-major order over all XCDs read
+// every row block 7.5x from the fabric: profiles/r3_pmc_shipping_kernels_bench_scale.txt, 41.8 GB for a 5.6 GB slab).
+__device__ __forceinline__ bool gram_item(int pairs, int nsplit, int& pair, int& split) {
+  const int per_xcd = gridDim.x >> 3;
+  // (nsplit < 0: dispatch order as it comes, BLADES_GRAM_XCD=0, for A/B runs)
+  const int id = nsplit < 0 ? (int)blockIdx.x : (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (nsplit < 0) nsplit = -nsplit;
+  if (id >= pairs * nsplit) return false;
+  split = id / pairs; pair = id - split * pairs;
+  return true;
+}
+
 template <int B>
 __global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict__ U, long ld, int K, long Dl,
-                                                        long cols_per_split, int ntile, int Kp,
+                                                        long cols_per_split, int ntile, int Kp, int nsplit,
                                                         float* __restrict__ slabs) {
   constexpr int T = B / 64;  // MFMA blocks per wave per dim
   __shared__ __attribute__((aligned(16))) float lds[2 * B * LDS_LD];
   float* As = lds;
   float* Bs = lds + B * LDS_LD;
   // decode upper-triangular tile pair
-  int pair = blockIdx.x, ti = 0;
+  int pair, split, ti = 0;
+  if (!gram_item(ntile * (ntile + 1) / 2, nsplit, pair, split)) return;  // (whole workgroup: no barrier is skipped)
   while (pair >= ntile - ti) { pair -= ntile - ti; ++ti; }
   const int tj = ti + pair;
-  const long c_begin = (long)blockIdx.y * cols_per_split;
+  const long c_begin = (long)split * cols_per_split;
   long c_end = c_begin + cols_per_split;
   if (c_end > Dl) c_end = Dl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict_
     }
   }
   // C/D map of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  float* slab = slabs + (long)blockIdx.y * Kp * Kp;
+  float* slab = slabs + (long)split * Kp * Kp;
 #pragma unroll
   for (int a = 0; a < T; ++a)
 #pragma unroll
@@ -142,16 +158,17 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256, 2) void gram_planes_kernel(const float* __restrict__ U, long ld, int K, long Dl,
-                                                             long cols_per_split, int ntile, int Kp,
+                                                             long cols_per_split, int ntile, int Kp, int nsplit,
                                                              float* __restrict__ slabs) {
   constexpr int B = 128, PLANE = B * 64;  // bytes of one plane image
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * PLANE];
   unsigned char* As = lds;
   unsigned char* Bs = lds + 3 * PLANE;
-  int pair = blockIdx.x, ti = 0;
+  int pair, split, ti = 0;
+  if (!gram_item(ntile * (ntile + 1) / 2, nsplit, pair, split)) return;  // (whole workgroup: no barrier is skipped)
   while (pair >= ntile - ti) { pair -= ntile - ti; ++ti; }
   const int tj = ti + pair;
-  const long c_begin = (long)blockIdx.y * cols_per_split;
+  const long c_begin = (long)split * cols_per_split;
   long c_end = c_begin + cols_per_split;
   if (c_end > Dl) c_end = Dl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void gram_planes_kernel(const float* __rest
     }
   }
   // C/D map of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
-  float* slab = slabs + (long)blockIdx.y * Kp * Kp;
+  float* slab = slabs + (long)split * Kp * Kp;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -290,11 +307,15 @@ BLADES_API void blades_gram(const float* U, long ld, int K, long Dl, float* slab
   if (Dl <= 0) { hipMemsetAsync(out, 0, sizeof(float) * K * K, st); return; }
   // BLADES_GRAM_IMPL=f32: the exact-fp32 MFMA kernel for every size (A/B runs); default: bf16 planes for 128-row tiles
   static const bool f32_only = [] { const char* e = getenv("BLADES_GRAM_IMPL"); return e && e[0] == 'f'; }();
+  const int grid = (pairs * nsplit + 7) / 8 * 8;
+  static const bool no_xcd = [] { const char* e = getenv("BLADES_GRAM_XCD"); return e && atoi(e) == 0; }();
+  if (no_xcd) nsplit = -nsplit;
   if (B == 64)
-    hipLaunchKernelGGL((gram_tile_kernel<64>), dim3(pairs, nsplit), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, slabs);
+    hipLaunchKernelGGL((gram_tile_kernel<64>), dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
   else if (f32_only)
-    hipLaunchKernelGGL((gram_tile_kernel<128>), dim3(pairs, nsplit), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, slabs);
+    hipLaunchKernelGGL((gram_tile_kernel<128>), dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
   else
-    hipLaunchKernelGGL(gram_planes_kernel, dim3(pairs, nsplit), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, slabs);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)K * K, 256)), dim3(256), 0, st, slabs, nsplit, Kp, K, B, out);
+    hipLaunchKernelGGL(gram_planes_kernel, dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)K * K, 256)), dim3(256), 0, st, slabs,
+                     nsplit < 0 ? -nsplit : nsplit, Kp, K, B, out);
 }
