@@ -15,6 +15,7 @@
 // Reductions are two-stage with fixed order (no float atomics): bitwise reproducible.
 #include "common.h"
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 
 namespace {
 
@@ -111,6 +112,53 @@ __global__ __launch_bounds__(TPB) void pcbn_reduce_kernel(const T* __restrict__ 
   }
 }
 
+// Sum of the per-chunk partials of 16 channels of one client by 16 thread groups (chunks k = part, part + 16, ...),
+// combined in a fixed order through LDS: with the statistics coming from a convolution's epilogue a client has one
+// chunk per output tile (256 on the 32 x 32 layers) and one thread per (client, channel) walked them serially —
+// 36 us per call, 3 % of the headline round for two tiny kernels per BatchNorm.
+constexpr int FIN_CH = 16, FIN_PARTS = TPB / FIN_CH;
+__device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial, int Kc, int C, int nchunk, int& c, int& ch,
+                                              double& s0, double& s1) {
+  __shared__ double red[FIN_PARTS][FIN_CH][2];
+  const int groups = (C + FIN_CH - 1) / FIN_CH;
+  c = blockIdx.x / groups;
+  const int chl = threadIdx.x & (FIN_CH - 1), part = threadIdx.x / FIN_CH;
+  ch = (blockIdx.x - c * groups) * FIN_CH + chl;
+  double a = 0.0, b = 0.0;
+  if (ch < C)
+    for (int k = part; k < nchunk; k += FIN_PARTS) {
+      const float2 q = *reinterpret_cast<const float2*>(partial + ((size_t)(c * nchunk + k) * C + ch) * 2);
+      a += (double)q.x; b += (double)q.y;
+    }
+  red[part][chl][0] = a; red[part][chl][1] = b;
+  __syncthreads();
+  if (part != 0 || ch >= C) return false;
+  s0 = 0.0; s1 = 0.0;
+#pragma unroll
+  for (int p = 0; p < FIN_PARTS; ++p) { s0 += red[p][chl][0]; s1 += red[p][chl][1]; }
+  return true;
+}
+
+// forward finalize, parallel over chunks: one workgroup per (client, 16 channels)
+__global__ __launch_bounds__(TPB) void pcbn_fwd_finalize_par_kernel(const float* __restrict__ partial, int Kc, int C,
+                                                                    int nchunk, int P, float eps,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int gstride,
+                                                                    float* __restrict__ mean, float* __restrict__ invstd,
+                                                                    float* __restrict__ scale, float* __restrict__ shift) {
+  int c, ch;
+  double s, ss;
+  if (!finalize_sums(partial, Kc, C, nchunk, c, ch, s, ss)) return;
+  const int i = c * C + ch;
+  const double m = s / P;
+  double var = ss / P - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[(size_t)c * gstride + ch] : 1.f, b = beta ? beta[(size_t)c * gstride + ch] : 0.f;
+  mean[i] = (float)m; invstd[i] = is;
+  scale[i] = g * is; shift[i] = b - (float)m * g * is;
+}
+
 // forward finalize: one thread per (client, channel)
 __global__ __launch_bounds__(TPB) void pcbn_fwd_finalize_kernel(const float* __restrict__ partial, int Kc, int C, int nchunk,
                                                                 int P, float eps, const float* __restrict__ gamma,
@@ -172,6 +220,33 @@ __global__ __launch_bounds__(TPB) void pcbn_fwd_apply_kernel(const T* __restrict
     // ReLU gate for the backward pass, 1 bit per element instead of re-reading y (2 bytes per element)
     if (mask != nullptr) mask[off >> 3] = (unsigned char)mb;
   }
+}
+
+// backward finalize, parallel over chunks (see finalize_sums)
+__global__ __launch_bounds__(TPB) void pcbn_bwd_finalize_par_kernel(const float* __restrict__ partial, int Kc, int C,
+                                                                    int nchunk, int P, const float* __restrict__ gamma,
+                                                                    int gstride, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    const float* __restrict__ coef, float* __restrict__ U,
+                                                                    long ld, long off_gamma, long off_beta, int accumulate,
+                                                                    float* __restrict__ k_scale, float* __restrict__ k_b,
+                                                                    float* __restrict__ k_c, int raw) {
+  int c, ch;
+  double sg, sgx;
+  if (!finalize_sums(partial, Kc, C, nchunk, c, ch, sg, sgx)) return;
+  const int i = c * C + ch;
+  if (raw) sgx = (double)invstd[i] * (sgx - (double)mean[i] * sg);
+  const float g = gamma ? gamma[(size_t)c * gstride + ch] : 1.f;
+  if (U != nullptr) {
+    float* row = U + (size_t)c * ld;
+    const float s = coef[c];
+    if (accumulate) { row[off_gamma + ch] += s * (float)sgx; row[off_beta + ch] += s * (float)sg; }
+    else { row[off_gamma + ch] = s * (float)sgx; row[off_beta + ch] = s * (float)sg; }
+  }
+  const float ks = g * invstd[i], kb = (float)(sg / P), kc = (float)(sgx / P);
+  k_scale[i] = ks;
+  k_b[i] = -ks * invstd[i] * kc;
+  k_c[i] = ks * (mean[i] * invstd[i] * kc - kb);
 }
 
 // backward finalize: dgamma/dbeta -> update-matrix rows (scaled), coefficient tables for apply
@@ -249,6 +324,12 @@ __global__ __launch_bounds__(TPB) void pcbn_bwd_apply_kernel(const T* __restrict
   }
 }
 
+// chunk-parallel finalize where a client has enough chunks to share out (BLADES_PCBN_FINALIZE=serial: never, for A/B)
+inline bool par_finalize(int nchunk) {
+  static const bool off = [] { const char* e = getenv("BLADES_PCBN_FINALIZE"); return e && e[0] == 's'; }();
+  return !off && nchunk >= 8;
+}
+
 inline int chunk_pixels(int C, int esize = 2) {
   int p = 262144 / (C * esize);
   if (p < 64) p = 64;
@@ -266,8 +347,12 @@ int pcbn_forward_t(const void* x, const void* res, const float* gamma, const flo
   if (pre_nchunk <= 0)
     hipLaunchKernelGGL((pcbn_reduce_kernel<0, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
                        (const T*)nullptr, nullptr, nullptr, nullptr, P, C, ppc, nch, partial);
-  hipLaunchKernelGGL(pcbn_fwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
-                     eps, gamma, beta, gstride, mean, invstd, scale, shift);
+  if (par_finalize(nch))
+    hipLaunchKernelGGL(pcbn_fwd_finalize_par_kernel, dim3(Kc * cdiv(C, FIN_CH)), dim3(TPB), 0, st, partial, Kc, C, nch,
+                       P, eps, gamma, beta, gstride, mean, invstd, scale, shift);
+  else
+    hipLaunchKernelGGL(pcbn_fwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
+                       eps, gamma, beta, gstride, mean, invstd, scale, shift);
   int gx = cdiv((long)P * (C / 8), TPB);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL((pcbn_fwd_apply_kernel<T>), dim3(gx, Kc), dim3(TPB), 0, st, (const T*)x, (const T*)res, scale,
@@ -285,9 +370,14 @@ int pcbn_backward_t(const void* x, const void* gy, const void* relu_mask, const 
   if (pre_nchunk <= 0)
     hipLaunchKernelGGL((pcbn_reduce_kernel<1, T>), dim3(nch, Kc), dim3(TPB), TPB * 16 * sizeof(float), st, (const T*)x,
                        (const T*)gy, (const unsigned char*)relu_mask, mean, invstd, P, C, ppc, nch, partial);
-  hipLaunchKernelGGL(pcbn_bwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
-                     gamma, gstride, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c,
-                     pre_nchunk > 0 ? 1 : 0);
+  if (par_finalize(nch))
+    hipLaunchKernelGGL(pcbn_bwd_finalize_par_kernel, dim3(Kc * cdiv(C, FIN_CH)), dim3(TPB), 0, st, partial, Kc, C, nch,
+                       P, gamma, gstride, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c,
+                       pre_nchunk > 0 ? 1 : 0);
+  else
+    hipLaunchKernelGGL(pcbn_bwd_finalize_kernel, dim3(cdiv((long)Kc * C, TPB)), dim3(TPB), 0, st, partial, Kc, C, nch, P,
+                       gamma, gstride, mean, invstd, coef, U, ld, off_gamma, off_beta, accumulate, k_scale, k_b, k_c,
+                       pre_nchunk > 0 ? 1 : 0);
   int gx = cdiv((long)P * (C / 8), TPB);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL((pcbn_bwd_apply_kernel<T>), dim3(gx, Kc), dim3(TPB), 0, st, (const T*)x, (const T*)gy,
