@@ -80,6 +80,13 @@ struct IgemmParams {
   int tap_w[MAXTAPS];         // index of tap t in the weight tensor
   int n_clients, imgs_per_client;  // per-client weights (local steps > 1): image n uses weight set n / imgs_per_client
   long wp_client_stride, bias_client_stride;  // elements between two clients' weight planes / biases
+  // Tile pixel handled by (fragment f, lane column li): perm[f * 16 + li].  Identity where the 16 pixels of a
+  // fragment sit in 16 consecutive LDS slots (32- and 16-pixel-wide rows); on narrower images a fragment spans
+  // several padded rows or images and consecutive pixels put two lanes of a ds_read_b128 service group on the same
+  // banks (PMC: 21.6 % conflict cycles on the 8x8 layers, 44 % on 4x4).  The bank of a fragment read depends on
+  // slot mod 8 only, and a read is conflict-free iff the slots of lanes li = 4..11 are distinct mod 8 and those of
+  // li = 0..3, 12..15 are: the host deals the tile's pixels to fragments accordingly (dispatch()).
+  unsigned short perm[256];
   unsigned long long* prof;   // PROF build: [16] cycle sums (see the kernel)
   int ablate;                 // diagnostics (BLADES_IGEMM_ABLATE): 1 no staging loads, 2 no commit, 4 no MFMAs
   int bdouble;                // two weight-tile images in LDS (where they fit): a step's successor tile is committed
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_v1_kernel(cons
   long out_pix[MF];
 #pragma unroll
   for (int pf = 0; pf < MF; ++pf) {
-    const int m = (wave * MF + pf) * 16 + li;
+    const int m = p.perm[(wave * MF + pf) * 16 + li];
     const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
     const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
     const bool ok = il < p.TI && sy0 + ry < p.Hs && img0 + il < p.N;
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
   // (the output pixel index is only needed by the epilogue and is recomputed there: nothing of it lives through the
   // K loop)
   auto pixel_of = [&](int pf, int& slot) -> long {
-    const int m = (wpix * NPF + pf) * 16 + li;
+    const int m = p.perm[(wpix * NPF + pf) * 16 + li];
     const int q = fdiv(m, p.inv_ws), sx = m - q * p.Ws;
     const int il = fdiv(q, p.inv_tr), ry = q - il * p.TR;
     const bool ok = il < p.TI && sy0 + ry < p.Hs && img0 + il < p.N;
@@ -1129,6 +1136,46 @@ int launch(const IgemmParams& p, hipStream_t st, bool rf) {
   return 0;
 }
 
+// pixel -> (fragment, lane) assignment of a tile, see IgemmParams::perm
+void build_perm(IgemmParams& p, int mf) {
+  const int BM = 64 * mf, nfrag = BM / 16;
+  for (int i = 0; i < 256; ++i) p.perm[i] = (unsigned short)(i < BM ? i : 0);
+  static const bool off = [] { const char* e = getenv("BLADES_IGEMM_PERM"); return e && atoi(e) == 0; }();
+  if (off) return;
+  // LDS slot of tile pixel m (the kernel's own formula; rows beyond the image keep the formula's slot: they only
+  // occur in a tile's last row band)
+  int slot[256];
+  for (int m = 0; m < BM; ++m) {
+    const int q = m / p.Ws, sx = m - q * p.Ws;
+    const int il = q / p.TR, ry = q - il * p.TR;
+    slot[m] = il < p.TI ? il * p.IS + ry * p.si * p.WS + sx * p.si + p.PL : p.PL;
+  }
+  auto clean = [&](const unsigned short* f) {  // conflict-free fragment?
+    unsigned a = 0, b = 0;
+    for (int li = 0; li < 16; ++li) {
+      const unsigned bit = 1u << (slot[f[li]] & 7);
+      unsigned& set = (li >= 4 && li < 12) ? a : b;
+      if (set & bit) return false;
+      set |= bit;
+    }
+    return true;
+  };
+  bool all_clean = true;
+  for (int f = 0; f < nfrag; ++f) all_clean = all_clean && clean(p.perm + f * 16);
+  if (all_clean) return;
+  // deal the pixels by residue: every fragment needs two pixels of each residue class (one per lane set)
+  int bucket[8][256], cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int m = 0; m < BM; ++m) { const int r = slot[m] & 7; bucket[r][cnt[r]++] = m; }
+  for (int r = 0; r < 8; ++r)
+    if (cnt[r] != 2 * nfrag) return;  // unbalanced geometry: keep the identity
+  static const int lanes_a[8] = {4, 5, 6, 7, 8, 9, 10, 11}, lanes_b[8] = {0, 1, 2, 3, 12, 13, 14, 15};
+  for (int f = 0; f < nfrag; ++f)
+    for (int r = 0; r < 8; ++r) {
+      p.perm[f * 16 + lanes_a[r]] = (unsigned short)bucket[r][2 * f];
+      p.perm[f * 16 + lanes_b[r]] = (unsigned short)bucket[r][2 * f + 1];
+    }
+}
+
 int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t st) {
   bool rf = false;
   const int mf = choose(p, npl, ay, ax, rf);
@@ -1138,6 +1185,7 @@ int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t 
   p.inv_ws = 1.0f / p.Ws; p.inv_tr = 1.0f / p.TR; p.inv_wi = 1.0f / p.Wi; p.inv_irwi = 1.0f / (p.IR * p.Wi);
   for (int t = 0; t < p.ntaps; ++t) p.tap_off[t] = (ay[t] - p.aymin) * p.WS + ax[t];
   p.n_ntiles = p.Cop / BN;
+  build_perm(p, mf);
   if (p.stats != nullptr) {
     const int per = stats_chunks(p, p.stats_B);
     if (per == 0 || npl == 1) return 6;
