@@ -586,7 +586,7 @@ class _PCBatchNormFn(torch.autograd.Function):
         ctx.mod, ctx.relu, ctx.has_res, ctx.use_hip = mod, relu, res is not None, use_hip
         ctx.save_for_backward(x, gate, mean, invstd)
         ctx.hint = None
-        if use_hip and _bn_bwd_in_dgrad() and x.dtype == torch.float32 and Kc:
+        if use_hip and mod.want_hint and _bn_bwd_in_dgrad() and x.dtype == torch.float32 and Kc:
             ctx.hint = mod.last_hint = BnBackHint(x, gate, x.shape[0] // Kc)
         return y
 
@@ -895,10 +895,14 @@ class PCBatchNorm2d(nn.Module):
         self.weight = bn.weight if bn.affine else None
         self.bias = bn.bias if bn.affine else None
         self.sink = sink
+        self.last_hint, self.want_hint = None, False
 
     def forward(self, x, residual=None, relu: bool = False, pre_stats=None):
         anchor = self.weight if self.weight is not None else x
         self.last_hint = None
+        # (inside the Function grad mode is off: decide here whether a backward pass can follow at all — evaluation
+        # must not keep the BatchNorm input alive through the hint)
+        self.want_hint = torch.is_grad_enabled() and x.requires_grad
         y = _PCBatchNormFn.apply(x, residual, anchor, self, relu, pre_stats)
         if self.last_hint is not None:
             y._bn_hint, self.last_hint = self.last_hint, None  # read by the convolution that consumes y

@@ -186,8 +186,20 @@ class ClientEngine:
                          and os.environ.get("BLADES_DISABLE_FUSED_PC") != "1")
         self.fused_pc_error = None
         # several local steps: per-client weights -> grouped wide-network executor, if the model passes its
-        # layout self-check (otherwise the torch.vmap path)
+        # layout self-check (otherwise the torch.vmap path).  Where the fused executor runs with per-client weights
+        # the grouped one is only its fallback: it is then built (and self-checked, which runs the library
+        # convolutions once) when a layer first declines, not at setup.
         self.grouped = None
+        self._grouped_ready = False
+        self._grouped_args = (task, dataset)
+        if not self.fused_pc:
+            self._ensure_grouped()
+
+    def _ensure_grouped(self):
+        if self._grouped_ready:
+            return
+        self._grouped_ready = True
+        task, dataset = self._grouped_args
         if self.nb > 1 and self.mode in ("auto", "batched", "fused") and self.Kloc > 0:
             from . import grouped
 
@@ -615,6 +627,7 @@ class ClientEngine:
                     losses = self.fused.run_per_client(W, X, Y, G)
                 except NotImplementedError as e:
                     self.fused_pc, self.fused_pc_error = False, str(e)
+                    self._ensure_grouped()
             if losses is not None:
                 pass
             elif self.grouped is not None:

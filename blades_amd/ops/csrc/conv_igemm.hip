@@ -947,28 +947,41 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_kernel(const I
 __global__ __launch_bounds__(256) void conv_wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
                                                          int Co, int Ci, int taps, int rows, int rows_pad, int k,
                                                          int k_pad, int transpose, int npl, long w_client_stride) {
+  // one thread = one lane's 8 consecutive k of a fragment (16 bytes per plane): with per-client weights (local steps
+  // > 1) this pass runs per layer, client and step, so it stores 16 bytes at a time instead of 2
   const size_t total = (size_t)taps * rows_pad * k_pad;
   w += (size_t)blockIdx.y * w_client_stride;          // one weight set per client (grid.y), planes [client][..]
   wp += (size_t)blockIdx.y * npl * total;
   const int nchunks = k_pad / KC, ntiles = rows_pad / BN;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    // i enumerates the destination order without the plane index: (t, chunk, tile, half, frag, lane, e)
-    const int e = (int)(i & 7), ln = (int)((i >> 3) & 63), frag = (int)((i >> 9) & 1), half = (int)((i >> 10) & 1);
-    size_t r = i >> 11;
+  const size_t n8 = total >> 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    // i enumerates the destination order without the plane index: (t, chunk, tile, half, frag, lane)
+    const int ln = (int)(i & 63), frag = (int)((i >> 6) & 1), half = (int)((i >> 7) & 1);
+    size_t r = i >> 8;
     const int tile = (int)(r % ntiles); r /= ntiles;
     const int chunk = (int)(r % nchunks);
     const int t = (int)(r / nchunks);
-    const int row = tile * BN + half * 32 + frag * 16 + (ln & 15), kk = chunk * KC + (ln >> 4) * 8 + e;
-    float v = 0.f;
-    if (row < rows && kk < k) {
-      const int co = transpose ? kk : row, ci = transpose ? row : kk;
-      v = w[((size_t)co * Ci + ci) * taps + t];
+    const int row = tile * BN + half * 32 + frag * 16 + (ln & 15), kk0 = chunk * KC + (ln >> 4) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = kk0 + e;
+      v[e] = 0.f;
+      if (row < rows && kk < k) {
+        const int co = transpose ? kk : row, ci = transpose ? row : kk;
+        v[e] = w[((size_t)co * Ci + ci) * taps + t];
+      }
     }
-    const size_t grp = i >> 10;  // (t, chunk, tile, half)
+    const size_t grp = i >> 7;  // (t, chunk, tile, half)
     for (int q = 0; q < npl; ++q) {
-      const __bf16 b = (__bf16)v;
-      wp[((grp * npl + q) * 2 + frag) * 512 + (size_t)ln * 8 + e] = __builtin_bit_cast(unsigned short, b);
-      v -= (float)b;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const __bf16 b0 = (__bf16)v[e], b1 = (__bf16)v[e + 1];
+        o[e >> 1] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+        v[e] -= (float)b0; v[e + 1] -= (float)b1;
+      }
+      *reinterpret_cast<u32x4*>(wp + ((grp * npl + q) * 2 + frag) * 512 + (size_t)ln * 8) = o;
     }
   }
 }
@@ -1272,7 +1285,7 @@ BLADES_API int blades_conv_wprep(const float* w, void* ws, int Co, int Ci, int k
   const int rows = mode == 0 ? Co : Ci, k = mode == 0 ? Ci : Co;
   const int rows_pad = round_up(rows, BN), k_pad = round_up(k, KC);
   const size_t total = (size_t)taps * rows_pad * k_pad;
-  int gx = cdiv((long)total, 256);
+  int gx = cdiv((long)(total / 8), 256);
   if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(conv_wprep_kernel, dim3(gx, n_clients), dim3(256), 0, st, w, (unsigned short*)ws, Co, Ci, taps,
                      rows, rows_pad, k, k_pad, mode, npl, w_client_stride);
