@@ -992,9 +992,9 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // longer takes buys a larger pixel tile (the 4x4 / 512-channel layers: 256 instead of 128 pixels, measured -12 %;
 // at equal tile size the two paths measured within 1-2 % of each other on the stride-1 layers and the LDS-staged
 // one faster on the short chunks of the strided segments: profiles/r3_conv_igemm_rf_ab_same_box.log)
-inline int rf_mode() {
-  static const int m = [] { const char* e = getenv("BLADES_IGEMM_RF"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-  return m;
+inline int rf_mode() {  // (read per call: the tests switch it inside one process)
+  const char* e = getenv("BLADES_IGEMM_RF");
+  return e ? (atoi(e) != 0 ? 1 : 0) : -1;
 }
 
 // tile choice over both weight paths; sets `rf`
@@ -1035,11 +1035,13 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax, bool rf) {
   int best_mf = 0;
   double best_cost = 0;
   IgemmParams best = p;
+  // BLADES_IGEMM_MF (tests, A/B runs): this tile size where it fits the geometry, else the planner's own choice
   const char* force = getenv("BLADES_IGEMM_MF");
+  for (int pass = force ? 0 : 1; pass < 2 && best_mf == 0; ++pass)
   for (int mf = 4; mf >= 1; mf >>= 1) {
     const int BM = 64 * mf;
     if (p.Ws > BM) continue;
-    if (force && atoi(force) != mf) continue;
+    if (pass == 0 && atoi(force) != mf) continue;
     // candidates: TI whole images per tile (largest first), then row bands of one image (TR rows, fewest first
     // that fits the 160 KB of LDS: the staged receptive field grows with stride and kernel size)
     int ti_max = p.Hs * p.Ws * 2 <= BM ? BM / (p.Hs * p.Ws) : 1;
@@ -1153,8 +1155,7 @@ int launch(const IgemmParams& p, hipStream_t st, bool rf) {
 void build_perm(IgemmParams& p, int mf) {
   const int BM = 64 * mf, nfrag = BM / 16;
   for (int i = 0; i < 256; ++i) p.perm[i] = (unsigned short)(i < BM ? i : 0);
-  static const bool off = [] { const char* e = getenv("BLADES_IGEMM_PERM"); return e && atoi(e) == 0; }();
-  if (off) return;
+  { const char* e = getenv("BLADES_IGEMM_PERM"); if (e && atoi(e) == 0) return; }
   // LDS slot of tile pixel m (the kernel's own formula; rows beyond the image keep the formula's slot: they only
   // occur in a tile's last row band)
   int slot[256];

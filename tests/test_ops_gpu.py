@@ -299,6 +299,18 @@ def test_fused_engine_gpu_matches_fp32_reference(dev, tmp_path, amp):
     assert float(rel.max()) < 0.2, rel
 
 
+def _igemm_path(monkeypatch, path):
+    """Environment of a conv_igemm variant: "rf" / "lds" weight path, optional "-mfN" pixel fragments per wave."""
+    for k in ("BLADES_IGEMM_RF", "BLADES_IGEMM_MF"):
+        monkeypatch.delenv(k, raising=False)
+    if path == "default":
+        return
+    kind, _, mf = path.partition("-mf")
+    monkeypatch.setenv("BLADES_IGEMM_RF", "1" if kind == "rf" else "0")
+    if mf:
+        monkeypatch.setenv("BLADES_IGEMM_MF", mf)
+
+
 def _fp64_fedsgd_rows(algo):
     """One FedSGD round in float64 straight from its definition (reference hot loop fllib/tasks/task.py:170-186 with
     client lr and one batch): row c = -lr * d loss(theta; first batch of client c) / d theta."""
@@ -431,10 +443,16 @@ def test_conv_wgrad_kernel(dev, Kc, B, Cin, Cout, H, ks, stride, pad, npl):
     (2, 16, 12, 12, 16, 3, 3, 0),
 ])
 @pytest.mark.parametrize("npl", [3, 2, 1])
-def test_conv_igemm_kernel(dev, N, Ci, H, W, Co, k, s, p, npl):
-    """Own forward / data-gradient convolution (ops/csrc/conv_igemm.hip) against an fp64 convolution."""
+@pytest.mark.parametrize("path", ["default", "rf", "rf-mf4", "lds-mf4", "rf-mf2"])
+def test_conv_igemm_kernel(dev, monkeypatch, N, Ci, H, W, Co, k, s, p, npl, path):
+    """Own forward / data-gradient convolution (ops/csrc/conv_igemm.hip) against an fp64 convolution — on the weight
+    path and tile size the planner picks for these small problems ("default": mostly 64-pixel tiles, LDS-staged
+    weights) and with the register-fed / LDS-staged weight paths and the large tiles of the bench-scale launches
+    forced (a tile size that does not fit a geometry falls back to the planner's choice)."""
     import torch.nn.functional as F
     from blades_amd import ops
+
+    _igemm_path(monkeypatch, path)
 
     h = ops._h()
     g = torch.Generator().manual_seed(N * 1000 + Ci)
@@ -463,13 +481,15 @@ def test_conv_igemm_kernel(dev, N, Ci, H, W, Co, k, s, p, npl):
     (24, 32, 32, 32, 64, 1, 1, 0, 4), (14, 20, 9, 9, 24, 5, 1, 2, 7),
 ])
 @pytest.mark.parametrize("npl", [3, 1])
-def test_conv_igemm_stats_planes_accumulate(dev, N, Ci, H, W, Co, k, s, p, B, npl):
+@pytest.mark.parametrize("path", ["default", "rf-mf4", "lds-mf4"])
+def test_conv_igemm_stats_planes_accumulate(dev, monkeypatch, N, Ci, H, W, Co, k, s, p, B, npl, path):
     """Many-tile launches of conv_igemm against fp64: forward with the BatchNorm partial sums from the epilogue, data
     gradient, ready-made weight planes (one split per round, bitwise equal to the per-call split) and the data
     gradient's accumulate mode (the other gradient branch of a residual block added in the epilogue)."""
     import torch.nn.functional as F
     from blades_amd import ops
 
+    _igemm_path(monkeypatch, path)
     h = ops._h()
     g = torch.Generator().manual_seed(N * 1000 + Ci)
     dt = torch.bfloat16 if npl == 1 else torch.float32
@@ -515,13 +535,15 @@ def test_conv_igemm_stats_planes_accumulate(dev, N, Ci, H, W, Co, k, s, p, B, np
     (3, 4, 64, 32, 32, 64, 3, 1, 1), (5, 3, 64, 16, 16, 128, 3, 2, 1), (4, 6, 128, 8, 8, 128, 3, 1, 1),
     (3, 8, 256, 4, 4, 256, 3, 1, 1), (7, 5, 64, 8, 8, 128, 1, 2, 0), (2, 12, 32, 4, 4, 64, 3, 1, 1),
 ])
-def test_conv_igemm_per_client_weights(dev, Kc, B, Ci, H, W, Co, k, s, p):
+@pytest.mark.parametrize("path", ["default", "rf", "rf-mf4"])
+def test_conv_igemm_per_client_weights(dev, monkeypatch, Kc, B, Ci, H, W, Co, k, s, p, path):
     """Per-client weight sets (local steps > 1): image n uses client n // B's weights and bias, taken as rows of a
     wider strided matrix like the engine's W.  Forward and data gradient against a per-client fp64 convolution
     (B not a power of two, 4x4 / 8x8 maps, stride 2)."""
     import torch.nn.functional as F
     from blades_amd import ops
 
+    _igemm_path(monkeypatch, path)
     h = ops._h()
     g = torch.Generator().manual_seed(Kc * 100 + Ci)
     nw = Co * Ci * k * k
@@ -1300,13 +1322,15 @@ def test_conv_epilogue_batchnorm_statistics(dev, Kc, B, Ci, HW, Co, k, s, p):
     (2, 16, 512, 4, 512, 3, 1, 1, True, True),   # sixteen images per tile (register-fed weight path)
     (2, 8, 128, 16, 256, 3, 2, 1, False, True),
 ])
-def test_conv_dgrad_epilogue_batchnorm_backward_sums(dev, Kc, B, Ci, HW, Co, k, s, p, acc, gate):
+@pytest.mark.parametrize("path", ["default", "rf", "lds-mf2"])
+def test_conv_dgrad_epilogue_batchnorm_backward_sums(dev, monkeypatch, Kc, B, Ci, HW, Co, k, s, p, acc, gate, path):
     """The data-gradient kernel's epilogue does the first pass of the BatchNorm backward behind its output
     (VERDICT r2 item 2): per (client, chunk, channel) the sums of g and g * x under the ReLU gate, g = the finished
     gradient.  They must equal an fp64 reduction of the stored gradient, and pcbn_backward fed with them must give
     what it computes with its own reduction pass (reference: BatchNorm2d backward over one client's batch)."""
     from blades_amd.ops import _hip as h
 
+    _igemm_path(monkeypatch, path)
     torch.manual_seed(2)
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)
     Ho = (HW + 2 * p - k) // s + 1
