@@ -46,8 +46,9 @@ def main():
     ap.add_argument("--adversary", default="ALIEAdversary")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=0,
-                    help="clients vectorised per kernel chunk (400 x 64 samples: 102 GB peak HBM on ResNet-18, +3 %% "
-                         "over 200; multi-GPU runs use at most half a rank's clients so the exchange overlaps)")
+                    help="clients vectorised per kernel chunk; default: the engine's rule (engine/trainer.py: 32 x 64 "
+                         "samples for fp32 planes on a large model, everything in one chunk on the small ones; multi-GPU "
+                         "runs use at most half a rank's clients so the exchange overlaps); bf16: 400")
     ap.add_argument("--amp", default="fp32", help="fp32 (reference precision, default) | bf16x3 | bf16")
     ap.add_argument("--samples-per-client", type=int, default=128)
     ap.add_argument("--local-steps", type=int, default=1, help="client SGD steps per round (1 = FedSGD headline)")
@@ -100,11 +101,13 @@ def main():
     K = args.clients
     f = int(round(args.malicious_frac * K))
     agg = {"type": args.aggregator}
-    # fp32 planes: the MFMA-bound kernels are already full at 40 clients x 64 samples, and the smaller working set
-    # (53 GB peak instead of 102 GB) is worth 5 % (profiles/r2_chunk_stream_sweep_fp32.txt, 32 clients on three
-    # streams: profiles/r2_chunk_stream_sweep_v6.txt); bf16 likes 400
-    chunk = args.chunk or (400 if args.amp == "bf16" else 32)
-    if world > 1:
+    # default: the engine's own rule — fp32 planes on a large model: 32 clients x 64 samples on three streams (the
+    # MFMA-bound kernels are full there and the smaller working set, 53 GB peak instead of 102 GB, is worth 5 %:
+    # profiles/r2_chunk_stream_sweep_fp32.txt, r2_chunk_stream_sweep_v6.txt); small models: all of a rank's clients in
+    # one chunk (two chunks of 24 cost 7-40 % on the 60-client configurations:
+    # profiles/r3_small_configs_one_chunk_vs_two.log); bf16 likes 400
+    chunk = args.chunk or (400 if args.amp == "bf16" else "auto")
+    if world > 1 and isinstance(chunk, int):
         # at least two chunks per rank, so the all-to-all of the first overlaps the training of the second
         chunk = max(1, min(chunk, -(-(K - f) // (2 * world))))
     root = tempfile.mkdtemp(prefix="blades_bench_")

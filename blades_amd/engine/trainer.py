@@ -84,7 +84,7 @@ class ClientEngine:
             # the smaller working set is worth 5 % (profiles/r2_chunk_stream_sweep_fp32.txt, ..._v6.txt)
             n_par = sum(p.numel() for p in task.model.parameters())
             if on_gpu and amp_dtype in ("auto", "fp32", "bf16x3", None) and n_par > 8_000_000:
-                clients_per_chunk = max(8, clients_per_chunk // 6)
+                clients_per_chunk = max(8, (32 * 64) // max(int(batch_size), 1))
         self.chunk = max(1, int(clients_per_chunk))
         self.eval_chunk = eval_clients_per_chunk or self.chunk
         self.num_classes = num_classes

@@ -1271,6 +1271,34 @@ def _w4(weight: torch.Tensor):
     return w.as_strided((Kc, N, K, 1, 1), (w.stride(0), K, 1, 1, 1))
 
 
+_pc_linear = _opt_sig("blades_pc_linear", [_P, _P, c_long, _P, c_long, _P] + [c_int] * 6 + [_P], c_int)
+# rows per client up to which per-client Linear layers read their fp32 weights directly (ops/csrc/pc_linear.hip): with
+# few rows the layer is bound by the weight bytes, and the separate plane split costs 2.5x those; with many rows per
+# client (token models) the planes are reused often enough for conv_igemm's large tiles to win
+_PC_LINEAR_MAX_ROWS = int(_os.environ.get("BLADES_PC_LINEAR_MAX_ROWS", "256"))
+
+
+def _pc_linear_call(a2, weight, bias, mode: int, npl: int):
+    """Per-client Linear forward (mode 0) / data gradient (mode 1) straight from the fp32 weights; None = not taken."""
+    if _pc_linear is None or weight.dim() != 3 or npl not in (2, 3) or a2.dtype != torch.float32:
+        return None
+    Kc, N_out, K_in = (int(v) for v in weight.shape)
+    M = int(a2.shape[0])
+    R = M // Kc
+    if R > _PC_LINEAR_MAX_ROWS or weight.stride(2) != 1 or weight.stride(1) != K_in:
+        return None
+    if bias is not None and mode == 0:
+        if bias.dim() != 2 or bias.stride(1) != 1 or bias.dtype != torch.float32:
+            return None
+    out = _empty((M, N_out if mode == 0 else K_in), dtype=torch.float32, device=a2.device)
+    b = bias if mode == 0 else None
+    rc = _pc_linear(_ptr(a2), _ptr(weight), int(weight.stride(0)), _ptr(b) if b is not None else None,
+                    int(b.stride(0)) if b is not None else 0, _ptr(out), Kc, R, K_in, N_out, mode, npl, _stream())
+    if rc != 0:
+        raise ValueError(f"pc_linear: rejected (rc={rc})")
+    return out
+
+
 def linear_forward(x, weight, bias, npl: int, planes=None):
     """``x [..., K] @ weight^T (+ bias)`` -> ``[..., N]`` in x's dtype."""
     if not linear_supported(x, weight, npl):
@@ -1280,6 +1308,10 @@ def linear_forward(x, weight, bias, npl: int, planes=None):
     N = int(weight.shape[-2])
     if weight.dim() == 3 and M % int(weight.shape[0]):
         raise ValueError("linear_forward: rows are not a multiple of the number of clients")
+    if weight.dim() == 3 and planes is None:
+        y = _pc_linear_call(x2, weight.detach(), bias, 0, npl)
+        if y is not None:
+            return y.reshape(*x.shape[:-1], N)
     y = _empty((M, N), dtype=x.dtype, device=x.device)
     xv = x2.as_strided((M, K, 1, 1), (K, 1, K, K))
     yv = y.as_strided((M, N, 1, 1), (N, 1, N, N))
@@ -1297,6 +1329,10 @@ def linear_dgrad(gy, weight, npl: int, planes=None):
     K = int(weight.shape[-1])
     if weight.dim() == 3 and M % int(weight.shape[0]):
         raise ValueError("linear_dgrad: rows are not a multiple of the number of clients")
+    if weight.dim() == 3 and planes is None:
+        dx = _pc_linear_call(g2, weight.detach(), None, 1, npl)
+        if dx is not None:
+            return dx.reshape(*gy.shape[:-1], K)
     dx = _empty((M, K), dtype=gy.dtype, device=gy.device)
     gv = g2.as_strided((M, N, 1, 1), (N, 1, N, N))
     dv = dx.as_strided((M, K, 1, 1), (K, 1, K, K))

@@ -69,6 +69,38 @@ __global__ __launch_bounds__(TPB) void bias_grad_partial_kernel(const T* __restr
   }
 }
 
+// fp32, C % 4 == 0: four channels (16 bytes) per lane, so a wave's load covers whole 128-byte lines of several rows
+__global__ __launch_bounds__(TPB) void bias_grad_partial4_kernel(const float* __restrict__ g, int R, int C, int rows_per_chunk,
+                                                                 int nchunk, int CL, float* __restrict__ partial) {
+  extern __shared__ float red[];  // [RL][CL][4] per channel pass
+  const int client = blockIdx.y, chunk = blockIdx.x;
+  const int RL = TPB / CL, cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int r0 = chunk * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > R) r1 = R;
+  const float* base = g + (size_t)client * R * C;
+  for (int c0 = 0; c0 < C; c0 += CL * 4) {
+    const int ch = c0 + cl * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < C)
+      for (int r = r0 + rl; r < r1; r += RL) {
+        const float4 t = *reinterpret_cast<const float4*>(base + (size_t)r * C + ch);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+    reinterpret_cast<float4*>(red)[rl * CL + cl] = a;
+    __syncthreads();
+    if (rl == 0 && ch < C) {
+      float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < RL; ++j) {
+        const float4 t = reinterpret_cast<const float4*>(red)[j * CL + cl];
+        s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((size_t)client * nchunk + chunk) * C + ch) = s4;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(TPB) void bias_grad_final_kernel(const float* __restrict__ partial, int Kc, int C, int nchunk,
                                                               const float* __restrict__ coef, float* __restrict__ U,
                                                               long ld, long off, int accumulate) {
@@ -111,6 +143,78 @@ __global__ __launch_bounds__(TPB) void maxpool_fwd_kernel(const T* __restrict__ 
     if (relu && !(best > 0.f)) { best = 0.f; bi = 255; }
     st1(y + i, best);
     idx[i] = (unsigned char)bi;
+  }
+}
+
+// fp32, C % 4 == 0: four channels per lane (16-byte loads / stores, one 4-byte load of the window positions); same
+// comparisons and the same order of additions per element as the one-channel kernels below
+__global__ __launch_bounds__(TPB) void maxpool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           unsigned char* __restrict__ idx, long total4, int H, int W, int C4,
+                                                           int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
+                                                           int relu) {
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long)gridDim.x * TPB) {
+    const int c4 = (int)(i % C4);
+    long t = i / C4;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const long n = t / Ho;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {255, 255, 255, 255};
+    for (int r = 0; r < kh; ++r) {
+      const int ih = oh * sh - ph + r;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int s = 0; s < kw; ++s) {
+        const int iw = ow * sw - pw + s;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const float4 q = reinterpret_cast<const float4*>(x)[((n * H + ih) * W + iw) * C4 + c4];
+        const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v[j] > best[j] || bi[j] == 255) { best[j] = v[j]; bi[j] = r * kw + s; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (relu && !(best[j] > 0.f)) { best[j] = 0.f; bi[j] = 255; }
+    reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
+    reinterpret_cast<unsigned*>(idx)[i] = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void maxpool_bwd4_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ idx,
+                                                           float* __restrict__ dx, long total4, int H, int W, int C4, int Ho,
+                                                           int Wo, int kh, int kw, int sh, int sw, int ph, int pw) {
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long)gridDim.x * TPB) {
+    const int c4 = (int)(i % C4);
+    long t = i / C4;
+    const int iw = (int)(t % W); t /= W;
+    const int ih = (int)(t % H);
+    const long n = t / H;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int oh_lo = (ih + ph - kh + 1 + sh - 1);
+    oh_lo = oh_lo <= 0 ? 0 : oh_lo / sh;
+    int oh_hi = (ih + ph) / sh;
+    if (oh_hi > Ho - 1) oh_hi = Ho - 1;
+    int ow_lo = (iw + pw - kw + 1 + sw - 1);
+    ow_lo = ow_lo <= 0 ? 0 : ow_lo / sw;
+    int ow_hi = (iw + pw) / sw;
+    if (ow_hi > Wo - 1) ow_hi = Wo - 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const int r = ih - (oh * sh - ph);
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const unsigned want = (unsigned)(r * kw + (iw - (ow * sw - pw)));
+        const long o = ((n * Ho + oh) * Wo + ow) * C4 + c4;
+        const unsigned m = reinterpret_cast<const unsigned*>(idx)[o];
+        if (((m & 0xffu) == want) | (((m >> 8) & 0xffu) == want) | (((m >> 16) & 0xffu) == want) | ((m >> 24) == want)) {
+          const float4 q = reinterpret_cast<const float4*>(gy)[o];
+          if ((m & 0xffu) == want) a[0] += q.x;
+          if (((m >> 8) & 0xffu) == want) a[1] += q.y;
+          if (((m >> 16) & 0xffu) == want) a[2] += q.z;
+          if ((m >> 24) == want) a[3] += q.w;
+        }
+      }
+    }
+    reinterpret_cast<float4*>(dx)[i] = make_float4(a[0], a[1], a[2], a[3]);
   }
 }
 
@@ -300,7 +404,12 @@ BLADES_API int blades_bias_grad(const void* g, int Kc, int R, int C, const float
   int CL = 1;
   while (CL < C && CL < TPB) CL <<= 1;  // channel lanes: a power of two <= 256
   const size_t lds = TPB * sizeof(float);
-  if (esize == 4)
+  if (esize == 4 && C % 4 == 0 && (uintptr_t)g % 16 == 0 && (uintptr_t)partial % 16 == 0) {
+    int CL4 = 1;
+    while (CL4 * 4 < C && CL4 < 64) CL4 <<= 1;  // lanes of four channels: at least four rows per block pass
+    hipLaunchKernelGGL(bias_grad_partial4_kernel, dim3(nch, Kc), dim3(TPB), 4 * lds, st, (const float*)g, R, C, rpc, nch,
+                       CL4, partial);
+  } else if (esize == 4)
     hipLaunchKernelGGL((bias_grad_partial_kernel<float>), dim3(nch, Kc), dim3(TPB), lds, st, (const float*)g, R, C, rpc,
                        nch, CL, partial);
   else if (esize == 2)
@@ -318,7 +427,10 @@ BLADES_API int blades_maxpool_forward(const void* x, void* y, unsigned char* idx
                                       hipStream_t st) {
   if (kh * kw > 254 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || N <= 0) return 1;
   const long total = N * Ho * Wo * C;
-  if (esize == 4)
+  if (esize == 4 && C % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)idx % 4 == 0)
+    hipLaunchKernelGGL(maxpool_fwd4_kernel, dim3(grid_for(total / 4, 16384)), dim3(TPB), 0, st, (const float*)x, (float*)y, idx,
+                       total / 4, H, W, C / 4, Ho, Wo, kh, kw, sh, sw, ph, pw, relu);
+  else if (esize == 4)
     hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(grid_for(total, 16384)), dim3(TPB), 0, st, (const float*)x,
                        (float*)y, idx, total, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw, relu);
   else if (esize == 2)
@@ -335,7 +447,10 @@ BLADES_API int blades_maxpool_backward(const void* gy, const unsigned char* idx,
                                        hipStream_t st) {
   if (kh * kw > 254 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || N <= 0) return 1;
   const long total = N * H * W * C;
-  if (esize == 4)
+  if (esize == 4 && C % 4 == 0 && (uintptr_t)gy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)idx % 4 == 0)
+    hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(grid_for(total / 4, 16384)), dim3(TPB), 0, st, (const float*)gy, idx,
+                       (float*)dx, total / 4, H, W, C / 4, Ho, Wo, kh, kw, sh, sw, ph, pw);
+  else if (esize == 4)
     hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(grid_for(total, 16384)), dim3(TPB), 0, st, (const float*)gy, idx,
                        (float*)dx, total, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw);
   else if (esize == 2)

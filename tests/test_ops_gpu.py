@@ -571,14 +571,21 @@ def test_conv_igemm_per_client_weights(dev, monkeypatch, Kc, B, Ci, H, W, Co, k,
 
 @pytest.mark.parametrize("M,K,N,Kc", [(3840, 784, 128, 1), (3840, 128, 256, 1), (3840, 256, 10, 1), (960, 2304, 600, 1),
                                       (960, 600, 120, 1), (4096, 128, 384, 1), (192, 784, 128, 3), (420, 2304, 600, 5),
-                                      (420, 120, 10, 7), (37, 50, 30, 1)])
+                                      (420, 120, 10, 7), (37, 50, 30, 1), (400, 96, 72, 2), (150, 130, 33, 3),
+                                      (320, 600, 10, 5), (2048, 128, 384, 2)])
 @pytest.mark.parametrize("npl", [3, 1])
-def test_linear_forward_dgrad_kernel(dev, M, K, N, Kc, npl):
-    """Own Linear forward / data-gradient GEMM (conv_igemm on the [M, K, 1, 1] view) against fp64:
-    the MLP / CNN / CCT shapes, shared weights and per-client weight sets taken as rows of a wider matrix."""
+@pytest.mark.parametrize("woff,direct", [(7, True), (8, True), (8, False)])
+def test_linear_forward_dgrad_kernel(dev, monkeypatch, M, K, N, Kc, npl, woff, direct):
+    """Own Linear forward / data-gradient GEMM against fp64: the MLP / CNN / CCT shapes, shared weights (conv_igemm on
+    the [M, K, 1, 1] view) and per-client weight sets taken as rows of a wider matrix — read as fp32
+    by pc_linear.hip (`direct`: 16-byte loads when the rows sit at an aligned offset, element loads otherwise, row /
+    feature / reduction tails, several row tiles per client) or through conv_igemm's plane split (many rows per client)."""
     from blades_amd import ops
 
     h = ops._h()
+    if Kc == 1 and (woff, direct) != (7, True):
+        pytest.skip("shared weights: one variant")
+    monkeypatch.setattr(h, "_PC_LINEAR_MAX_ROWS", 256 if direct else 0)
     g = torch.Generator().manual_seed(M + K + N)
     dt = torch.bfloat16 if npl == 1 else torch.float32
     x = torch.randn(M, K, generator=g).to(dt)
@@ -591,14 +598,14 @@ def test_linear_forward_dgrad_kernel(dev, M, K, N, Kc, npl):
         y_ref = x.double() @ wr.t() + b.double()
         dx_ref = gy.double() @ wr
     else:
-        Wm = torch.randn(Kc, 7 + N * K + N + 3, generator=g) / K ** 0.5
+        Wm = torch.randn(Kc, woff + N * K + N + (8 - (woff + N * K + N) % 8), generator=g) / K ** 0.5
         Wd = Wm.to(dev)
-        wd = Wd.as_strided((Kc, N, K), (Wd.stride(0), K, 1), 7)
-        bd = Wd.as_strided((Kc, N), (Wd.stride(0), 1), 7 + N * K)
+        wd = Wd.as_strided((Kc, N, K), (Wd.stride(0), K, 1), woff)
+        bd = Wd.as_strided((Kc, N), (Wd.stride(0), 1), woff + N * K)
         R = M // Kc
-        wr = Wm[:, 7: 7 + N * K].reshape(Kc, N, K)
+        wr = Wm[:, woff: woff + N * K].reshape(Kc, N, K)
         wr = (wr.to(dt) if npl == 1 else wr).double()
-        br = Wm[:, 7 + N * K: 7 + N * K + N].double()
+        br = Wm[:, woff + N * K: woff + N * K + N].double()
         y_ref = torch.bmm(x.double().reshape(Kc, R, K), wr.transpose(1, 2)) + br.unsqueeze(1)
         dx_ref = torch.bmm(gy.double().reshape(Kc, R, N), wr)
         y_ref, dx_ref = y_ref.reshape(M, N), dx_ref.reshape(M, K)
@@ -644,7 +651,8 @@ def test_bias_grad_kernel(dev, Kc, R, C, dt):
 
 
 @pytest.mark.parametrize("N,C,H,W,k,s,p", [(6, 32, 28, 28, 2, 2, 0), (6, 64, 12, 12, 2, 2, 0), (5, 64, 32, 32, 3, 2, 1),
-                                            (3, 24, 15, 17, 3, 2, 1), (2, 8, 9, 9, 3, 1, 1), (2, 16, 7, 7, 2, 2, 0)])
+                                            (3, 24, 15, 17, 3, 2, 1), (2, 8, 9, 9, 3, 1, 1), (2, 16, 7, 7, 2, 2, 0),
+                                            (2, 6, 9, 9, 3, 2, 1), (3, 10, 8, 8, 2, 2, 0)])
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_maxpool_kernels(dev, N, C, H, W, k, s, p, relu, dt):
