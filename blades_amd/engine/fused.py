@@ -108,8 +108,13 @@ _BN_STATS_IN_CONV = _os.environ.get("BLADES_BN_STATS_IN_CONV", "1") != "0"
 _STEM_IM2COL = _os.environ.get("BLADES_STEM_IM2COL", "1") != "0"
 
 
+def _stem_width(Ci: int, k: int, cuda: bool) -> int:
+    """Channels per pixel of the stem's im2col tensor (16 for single-channel images on the GPU, else 32)."""
+    return _hipmod().stem_width(Ci, k) if cuda else 32
+
+
 def _stem_im2col(x: torch.Tensor, k: int, pad: int) -> torch.Tensor:
-    """[N, Ci, H, W] -> [N, 32, H, W] (channels-last storage), channel ci*k*k + r*k + s = x[ci, h + r - pad,
+    """[N, Ci, H, W] -> [N, 16 | 32, H, W] (channels-last storage), channel ci*k*k + r*k + s = x[ci, h + r - pad,
     w + s - pad], zero beyond Ci*k*k: the row order of ``weight.reshape(Co, Ci*k*k)``."""
     N, Ci, H, W = x.shape
     if x.is_cuda and x.dtype == torch.float32:
@@ -223,7 +228,8 @@ class _PCConvFn(torch.autograd.Function):
                 w2 = mod._planes["stem_w"]
             else:
                 wk = mod.sink.param(weight).detach()
-                w2 = F.pad(wk.reshape(*wk.shape[:-3], Ci * 9), (0, 32 - Ci * 9)).reshape(*wk.shape[:-3], 32, 1, 1)
+                wd = int(col.shape[1])
+                w2 = F.pad(wk.reshape(*wk.shape[:-3], Ci * 9), (0, wd - Ci * 9)).reshape(*wk.shape[:-3], wd, 1, 1)
             ctx.stem = True
             ctx.save_for_backward(col, w2)
             if want_stats and _BN_STATS_IN_CONV:
@@ -355,9 +361,10 @@ class PCConv2d(nn.Module):
         if (_STEM_IM2COL and npl > 1 and Ci <= 3 and kh == kw == 3 and list(self.stride) == [1, 1]
                 and list(self.padding) == [1, 1]):
             w2 = pl.get("stem_w")
+            wd = _stem_width(Ci, 3, True)
             if w2 is None:
-                w2 = pl["stem_w"] = torch.zeros((Co, 32, 1, 1), device=w.device, dtype=torch.float32)
-            w2.view(Co, 32)[:, : Ci * 9].copy_(w.reshape(Co, Ci * 9))
+                w2 = pl["stem_w"] = torch.zeros((Co, wd, 1, 1), device=w.device, dtype=torch.float32)
+            w2.view(Co, wd)[:, : Ci * 9].copy_(w.reshape(Co, Ci * 9))
             pl["stem"] = h.conv_planes(w2, 0, npl, out=pl.get("stem"))
 
     def planes(self, kind: str):

@@ -1115,15 +1115,27 @@ def _conv_call(inp, weight, bias, out, N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, 
 
 
 _stem_im2col_c = _sig("blades_stem_im2col", [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int)
+_stem_im2col_w = _opt_sig("blades_stem_im2col_w", [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int)
+
+
+def stem_width(Ci: int, k: int) -> int:
+    """Channels per pixel of the stem's im2col tensor: 16 where ``Ci*k*k`` fits (single-channel images: half the bytes
+    of the layer's three passes over that tensor), else 32."""
+    return 16 if Ci * k * k <= 16 and _stem_im2col_w is not None else 32
 
 
 def stem_im2col(x: torch.Tensor, k: int, pad: int) -> torch.Tensor:
-    """fp32 channels-last ``[N, Ci, H, W]`` (``Ci*k*k <= 32``) -> ``[N, 32, H, W]`` channels-last with channel
+    """fp32 channels-last ``[N, Ci, H, W]`` (``Ci*k*k <= 32``) -> ``[N, stem_width, H, W]`` channels-last with channel
     ``ci*k*k + r*k + s`` = the input under tap ``(r, s)`` (zero padding, zero beyond ``Ci*k*k``)."""
     _chk_nhwc(x, "x", torch.float32)
     N, Ci, H, W = x.shape
-    out = _empty((N, 32, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    if _stem_im2col_c(_ptr(x), _ptr(out), N, H, W, Ci, int(k), int(pad), _stream()) != 0:
+    wd = stem_width(Ci, k)
+    out = _empty((N, wd, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if wd == 32:
+        rc = _stem_im2col_c(_ptr(x), _ptr(out), N, H, W, Ci, int(k), int(pad), _stream())
+    else:
+        rc = _stem_im2col_w(_ptr(x), _ptr(out), N, H, W, Ci, int(k), int(pad), wd, _stream())
+    if rc != 0:
         raise ValueError(f"stem_im2col: unsupported shape Ci={Ci} k={k}")
     return out
 

@@ -1,19 +1,20 @@
 // im2col of a first-layer ("stem") convolution input: x [N][H][W][Ci] fp32 (channels-last, Ci * k * k <= 32) ->
-// out [N][H][W][32], channel ci*k*k + r*k + s = x[n][h + r - pad][w + s - pad][ci], zero beyond Ci*k*k and outside
-// the image — the row order of weight.reshape(Co, Ci*k*k).  The engine then runs the stem as a 1x1 convolution
+// out [N][H][W][Wd] (Wd = 16 when Ci * k * k fits — single-channel images — else 32), channel ci*k*k + r*k + s =
+// x[n][h + r - pad][w + s - pad][ci], zero beyond Ci*k*k and outside the image — the row order of weight.reshape(Co, Ci*k*k).  The engine then runs the stem as a 1x1 convolution
 // over this tensor (one 32-wide K-step instead of k*k padded ones) and its weight gradient as a plain GEMM
 // (engine/fused.py::_PCConvFn; reference layer: fllib/models/cifar10/resnet_cifar.py conv1).
-// One thread per (pixel, 4-channel group): 16-byte stores, a pixel's 128 bytes are written by 8 adjacent lanes.
+// One thread per (pixel, 4-channel group): 16-byte stores, a pixel's Wd * 4 bytes are written by adjacent lanes.
 #include "common.h"
 
 namespace {
 
+template <int GROUPS>  // Wd / 4
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, float* __restrict__ out, long npix,
                                                           int H, int W, int Ci, int k, int pad) {
   const int kk = k * k, K = Ci * kk;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix * 8; i += (long)gridDim.x * 256) {
-    const long pix = i >> 3;
-    const int g = (int)(i & 7);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix * GROUPS; i += (long)gridDim.x * 256) {
+    const long pix = i / GROUPS;
+    const int g = (int)(i % GROUPS);
     const int w = (int)(pix % W);
     const long t = pix / W;
     const int h = (int)(t % H);
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
         if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v[j] = x[((n * H + ih) * W + iw) * Ci + ci];
       }
     }
-    *reinterpret_cast<float4*>(out + pix * 32 + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(out + pix * (GROUPS * 4) + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -83,13 +84,21 @@ BLADES_API int blades_im2col(const void* x, void* col, long N, int H, int W, int
   return 0;
 }
 
-// returns 0 ok; 1 = unsupported shape
+// returns 0 ok; 1 = unsupported shape.  wd: channels of `out` per pixel, 16 or 32 (>= Ci * k * k)
+BLADES_API int blades_stem_im2col_w(const float* x, float* out, int N, int H, int W, int Ci, int k, int pad, int wd,
+                                    hipStream_t st) {
+  if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || k <= 0 || Ci * k * k > wd || pad < 0 || (wd != 16 && wd != 32)) return 1;
+  const long npix = (long)N * H * W;
+  long blocks = (npix * (wd / 4) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (wd == 16)
+    hipLaunchKernelGGL(stem_im2col_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, x, out, npix, H, W, Ci, k, pad);
+  else
+    hipLaunchKernelGGL(stem_im2col_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, x, out, npix, H, W, Ci, k, pad);
+  return 0;
+}
+
 BLADES_API int blades_stem_im2col(const float* x, float* out, int N, int H, int W, int Ci, int k, int pad,
                                   hipStream_t st) {
-  if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || k <= 0 || Ci * k * k > 32 || pad < 0) return 1;
-  const long npix = (long)N * H * W;
-  long blocks = (npix * 8 + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, out, npix, H, W, Ci, k, pad);
-  return 0;
+  return blades_stem_im2col_w(x, out, N, H, W, Ci, k, pad, 32, st);
 }

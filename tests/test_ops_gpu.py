@@ -1400,30 +1400,38 @@ def test_conv_epilogue_statistics_decline_straddling_tiles(dev):
 
 
 @pytest.mark.parametrize("npl", [3, 2])
-def test_stem_as_im2col_pointwise_convolution(dev, npl):
-    """The engine runs a 3-channel 3x3 stem as a 1x1 convolution over an im2col tensor (27 real of 32 channels):
-    forward and per-client weight gradient (``cin_store`` = 27, rows laid out as [Co][Ci][3][3]) against torch."""
+@pytest.mark.parametrize("Ci,Co,HW", [(3, 64, 32), (1, 32, 28)])
+def test_stem_as_im2col_pointwise_convolution(dev, npl, Ci, Co, HW):
+    """The engine runs a 3x3 stem as a 1x1 convolution over an im2col tensor (3 channels: 27 real of 32; one channel:
+    9 of 16): forward and per-client weight gradient (``cin_store`` = Ci * 9, rows laid out as [Co][Ci][3][3]) against
+    torch."""
     import torch.nn.functional as F
     from blades_amd.engine.fused import _stem_im2col
     from blades_amd.ops import _hip as h
 
     torch.manual_seed(3)
-    Kc, B, Co = 3, 4, 64
-    x = torch.randn(Kc * B, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
-    w = torch.randn(Co, 3, 3, 3, device=dev) / 5
-    gy = torch.randn(Kc * B, Co, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    Kc, B = 3, 4
+    K9 = Ci * 9
+    wd = 16 if K9 <= 16 else 32
+    x = torch.randn(Kc * B, Ci, HW, HW, device=dev).contiguous(memory_format=torch.channels_last)
+    if Ci == 1:
+        x = x.as_strided(x.shape, (x.stride(0), 1, x.stride(2), x.stride(3)))
+    w = torch.randn(Co, Ci, 3, 3, device=dev) / 5
+    gy = torch.randn(Kc * B, Co, HW, HW, device=dev).contiguous(memory_format=torch.channels_last)
     col = _stem_im2col(x, 3, 1)
-    assert col.shape == (Kc * B, 32, 32, 32) and col.is_contiguous(memory_format=torch.channels_last)
-    w2 = F.pad(w.reshape(Co, 27), (0, 5)).reshape(Co, 32, 1, 1)
+    assert col.shape == (Kc * B, wd, HW, HW) and col.is_contiguous(memory_format=torch.channels_last)
+    ref_col = F.unfold(x.contiguous(), 3, padding=1).reshape(Kc * B, K9, HW, HW)
+    assert torch.equal(col[:, :K9], ref_col) and float(col[:, K9:].abs().max()) == 0
+    w2 = F.pad(w.reshape(Co, K9), (0, wd - K9)).reshape(Co, wd, 1, 1)
     y = h.conv_forward(col, w2, None, 1, 0, npl)
     tol = 2e-5 if npl == 3 else 2e-3
     torch.testing.assert_close(y, F.conv2d(x, w, None, 1, 1), rtol=tol, atol=tol)
-    U = torch.full((Kc, Co * 27 + 9), 7.0, device=dev)
+    U = torch.full((Kc, Co * K9 + 9), 7.0, device=dev)
     coef = torch.tensor([1.0, -0.5, 2.0], device=dev)
-    assert h.conv_wgrad_(col, gy, Kc, U, 4, coef, False, 1, 1, 0, npl, cin_store=27)
+    assert h.conv_wgrad_(col, gy, Kc, U, 4, coef, False, 1, 1, 0, npl, cin_store=K9)
     ref = torch.stack([torch.ops.aten.convolution_backward(gy[c * B:(c + 1) * B], x[c * B:(c + 1) * B], w, None, [1, 1],
                                                            [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
                        * coef[c] for c in range(Kc)])
-    got = U[:, 4:4 + Co * 27].reshape(Kc, Co, 3, 3, 3)
+    got = U[:, 4:4 + Co * K9].reshape(Kc, Co, Ci, 3, 3)
     torch.testing.assert_close(got, ref, rtol=tol, atol=tol * float(ref.abs().max()))
-    assert float((U[:, :4] - 7).abs().max()) == 0 and float((U[:, 4 + Co * 27:] - 7).abs().max()) == 0
+    assert float((U[:, :4] - 7).abs().max()) == 0 and float((U[:, 4 + Co * K9:] - 7).abs().max()) == 0
