@@ -28,6 +28,19 @@ class Centeredclipping(Aggregator):
         if self.momentum is None or self.momentum.shape[0] != U.shape[1]:
             self.momentum = torch.zeros(U.shape[1], device=U.device, dtype=torch.float32)
         m = self.momentum.to(U.device)
+        if 1 < K <= ops.smallk_max(U.device) and self.n_iter and self.n_iter > 1:
+            # Small client counts: every iterate is c0 m_0 + c^T U, so the iterations run in coefficient space on the
+            # Gram matrix (ops/csrc/smallk.hip) — three passes over U (Gram, U m_0, final combination) instead of two per
+            # iteration.  (At K = 1000 the Gram matrix is matrix-core-bound and costs as much as the ten passes.)
+            G = ops.gram(U)
+            pm = torch.cat([torch.mv(U, m), (m * m).sum().reshape(1)])
+            if ctx.distributed:
+                ctx.all_reduce(G)
+                ctx.all_reduce(pm)
+            cc = ops.cclip(G, pm[:K], pm[K:], int(self.n_iter), float(self.tau))
+            m = m * cc[0].float() + ops.weighted_col_sum(U, cc[1:].float())
+            self.momentum = m
+            return m.clone()
         for _ in range(self.n_iter):
             d2 = ops.sqdist_to(U, m)
             if ctx.distributed:

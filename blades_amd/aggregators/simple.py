@@ -83,6 +83,11 @@ class GeoMed(Aggregator):
         G = ops.gram(U)
         if ctx.distributed:
             ctx.all_reduce(G)
+        if U.shape[0] <= ops.smallk_max(U.device):
+            # small client counts: all iterations in one launch (the loop below is ~20 tiny kernels per iteration)
+            alpha, iters = ops.weiszfeld(G, w0, int(self.maxiter), float(self.eps), float(self.ftol))
+            self.last_info = {"weiszfeld_iters": iters, "method": "gram"}
+            return ops.weighted_col_sum(U, alpha)
         G = G.double()
         diag = torch.diagonal(G)
         w0d = w0.double()
@@ -118,7 +123,8 @@ class GeoMed(Aggregator):
             w0 = torch.full((K,), 1.0 / K, device=U.device, dtype=torch.float32)
         else:
             w0 = weights.to(device=U.device, dtype=torch.float32)
-        if self.method == "gram" or (self.method == "auto" and K * U.shape[1] * ctx.world_size >= 1e8):
+        if self.method == "gram" or (self.method == "auto" and (K * U.shape[1] * ctx.world_size >= 1e8
+                                                                or K <= ops.smallk_max(U.device))):
             return self._aggregate_gram(U, ctx, w0)
         median = ops.weighted_col_sum(U, w0 / w0.sum())
         dist = self._dist(U, median, ctx)
@@ -177,21 +183,15 @@ class DnC(Aggregator):
     def _sample_columns(self, d_total: int, device) -> torch.Tensor:
         # Same index set on every rank: a private CPU generator seeded from
         # (seed, call counter).  sub_dim draws without replacement.
-        g = torch.Generator()
-        g.manual_seed(self._seed * 1000003 + self._calls)
+        # numpy's Generator.choice draws n distinct ids in O(n) (no O(D) permutation; 0.1 ms for 10 000 of 11 M — the
+        # unique()-based rejection draw it replaces took 0.5 ms per iteration)
+        import numpy as np
+
+        rng = np.random.Generator(np.random.PCG64(self._seed * 1000003 + self._calls))
         self._calls += 1
         n = min(self.sub_dim, d_total)
-        if d_total <= 4 * n:
-            idx = torch.randperm(d_total, generator=g)[:n]
-        else:
-            # rejection-free draw of n distinct ids without an O(D) permutation
-            cand = torch.randint(0, d_total, (int(n * 1.3) + 16,), generator=g)
-            idx = torch.unique(cand, sorted=False)
-            while idx.numel() < n:
-                cand = torch.randint(0, d_total, (n,), generator=g)
-                idx = torch.unique(torch.cat([idx, cand]), sorted=False)
-            idx = idx[torch.randperm(idx.numel(), generator=g)[:n]]
-        return idx.to(device)
+        idx = rng.choice(d_total, size=n, replace=False, shuffle=False)
+        return torch.from_numpy(idx.astype(np.int64)).to(device, non_blocking=True)
 
     def aggregate(self, U, ctx):
         K = U.shape[0]

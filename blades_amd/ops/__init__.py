@@ -199,10 +199,30 @@ def add_normal_rows_(U, rows, seed, stream, col_offset, d_total, mean, std, over
 
 
 def power_iteration_top(G, iters=8):
-    """Top eigenvector of the K x K Gram matrix (DnC's outlier direction).  Deliberately NOT a hand-written kernel:
-    K is the number of clients (<= a few thousand), so this is ``iters`` K x K matrix-vector products — microseconds of
-    library GEMV on either device (DnC at K = 1000: 8 x 1 M-element products), and it stays on the device (no sync)."""
+    """Top eigenvector of the K x K Gram matrix (DnC's outlier direction): the direction ``G^(64 + iters) v0``.
+    Small client counts (K <= 128, the reference's 60-client experiments): one launch of ops/csrc/smallk.hip with G in
+    LDS — the ~30 library calls of the reference form cost 0.7 ms of launch overhead per call at that size.  Larger K:
+    six squarings + ``iters`` matrix-vector products on library GEMMs (K = 1000: 6 GEMMs of 1000^3), no host sync."""
+    if G.is_cuda and not _FORCE_REFERENCE and G.dtype == torch.float32 and 1 <= G.shape[0] <= _h().SMALLK_MAX:
+        return _h().power_top(G, 64 + int(iters))
     return ref.power_iteration_top(G, iters)
+
+
+def smallk_max(device) -> int:
+    """Largest client count the single-launch Gram-space solvers take on this device (0: none)."""
+    if getattr(device, "type", str(device)) != "cuda" or _FORCE_REFERENCE:
+        return 0
+    return int(_h().SMALLK_MAX)
+
+
+def cclip(G, p, mm, n_iter, tau):
+    """Centred-clipping coefficients (c0, c) from the Gram matrix in one launch (K <= smallk_max)."""
+    return _h().cclip(G, p, mm, n_iter, tau)
+
+
+def weiszfeld(G, w0, maxiter, eps, ftol):
+    """Geometric-median coefficients from the Gram matrix in one launch (K <= smallk_max): (alpha, iterations)."""
+    return _h().weiszfeld(G, w0, maxiter, eps, ftol)
 
 
 def ce_topk(logits, labels, ks=(1,)):

@@ -329,6 +329,56 @@ def gram(U):
     return out
 
 
+_smallk_max = _opt_sig("blades_smallk_max", [], c_int)
+_power_top = _opt_sig("blades_power_top", [_P, c_int, c_int, _P, _P], c_int)
+_weiszfeld = _opt_sig("blades_weiszfeld", [_P, _P, c_int, c_int, ctypes.c_double, ctypes.c_double, _P, _P, _P], c_int)
+_cclip = _opt_sig("blades_cclip", [_P, _P, _P, c_int, c_int, ctypes.c_double, _P, _P], c_int)
+SMALLK_MAX = int(_smallk_max()) if _smallk_max is not None else 0
+
+
+def cclip(G, p, mm, n_iter: int, tau: float):
+    """Centred-clipping iterations in coefficient space (K <= SMALLK_MAX): fp64 ``[1 + K]`` = (c0, c) with
+    ``m_n = c0 m_0 + c^T X``, from ``G = X X^T``, ``p = X m_0`` and ``mm = |m_0|^2`` (a one-element tensor)."""
+    K = int(G.shape[0])
+    if not (G.is_cuda and G.dtype == torch.float32 and G.dim() == 2 and G.shape[1] == K and 1 <= K <= SMALLK_MAX):
+        raise ValueError(f"cclip: expected a CUDA fp32 [K, K] matrix with K <= {SMALLK_MAX}")
+    G = G.contiguous()
+    p = _vec(p, K, G.device, name="p")
+    mm = mm.reshape(1).to(device=G.device, dtype=torch.float32)
+    out = torch.empty(1 + K, dtype=torch.float64, device=G.device)
+    if _cclip(_ptr(G), _ptr(p), _ptr(mm), K, int(n_iter), float(tau), _ptr(out), _stream()) != 0:
+        raise ValueError("cclip: rejected")
+    return out
+
+
+def power_top(G, steps: int):
+    """Top eigenvector of a symmetric PSD fp32 ``[K, K]`` matrix, K <= SMALLK_MAX, by ``steps`` normalised power steps
+    in one launch (ops/csrc/smallk.hip)."""
+    K = int(G.shape[0])
+    if not (G.is_cuda and G.dtype == torch.float32 and G.dim() == 2 and G.shape[1] == K and 1 <= K <= SMALLK_MAX):
+        raise ValueError(f"power_top: expected a CUDA fp32 [K, K] matrix with K <= {SMALLK_MAX}")
+    G = G.contiguous()
+    out = _empty(K, device=G.device)
+    if _power_top(_ptr(G), K, int(steps), _ptr(out), _stream()) != 0:
+        raise ValueError("power_top: rejected")
+    return out
+
+
+def weiszfeld(G, w0, maxiter: int, eps: float, ftol: float):
+    """Weiszfeld iterations of the geometric median in coefficient space on the Gram matrix ``G`` (fp32 ``[K, K]``,
+    K <= SMALLK_MAX), fp64 arithmetic, one launch.  Returns (alpha fp32 ``[K]``, iterations run as an int32 tensor)."""
+    K = int(G.shape[0])
+    if not (G.is_cuda and G.dtype == torch.float32 and G.dim() == 2 and G.shape[1] == K and 1 <= K <= SMALLK_MAX):
+        raise ValueError(f"weiszfeld: expected a CUDA fp32 [K, K] matrix with K <= {SMALLK_MAX}")
+    G = G.contiguous()
+    w0 = _vec(w0, K, G.device, name="w0")
+    alpha = _empty(K, device=G.device)
+    iters = torch.empty(1, dtype=torch.int32, device=G.device)
+    if _weiszfeld(_ptr(G), _ptr(w0), K, int(maxiter), float(eps), float(ftol), _ptr(alpha), _ptr(iters), _stream()) != 0:
+        raise ValueError("weiszfeld: rejected")
+    return alpha, iters
+
+
 def server_step_(theta, buf, agg, lr, momentum, first):
     n = theta.numel()
     for t in (theta, agg) + ((buf,) if momentum != 0.0 else ()):

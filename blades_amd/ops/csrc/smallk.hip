@@ -1,0 +1,197 @@
+// Single-workgroup solvers on the K x K Gram matrix for small client counts (K <= 128: the reference's own experiments
+// run 60 clients, blades/tuned_examples/*.yaml).  At that size the iterations of the Gram-space aggregators are a few
+// thousand multiply-adds each, and a Python loop of library calls spends 10 us of launch overhead on every one of them
+// (GeoMed: ~20 tiny kernels x up to 100 Weiszfeld iterations = up to 10 ms on a 34 ms ResNet-10 round; DnC: 0.7 ms per
+// power iteration call, five calls per round).  Here the whole iteration runs in one launch with G resident in LDS.
+//
+//   power_top   top eigenvector of a symmetric PSD G by `steps` normalised power steps from the reference's start
+//               vector (ops/reference.py::power_iteration_top does 6 squarings + 8 steps = the direction G^72 v0)
+//   weiszfeld   geometric median in coefficient space (aggregators/simple.py::GeoMed._aggregate_gram; reference
+//               blades/aggregators/aggregators.py:51-110): alpha <- normalise(w0 / max(dist, eps)),
+//               dist_i = sqrt(max(G_ii - 2 (G alpha)_i + alpha^T G alpha, 0)), until |obj - obj'| <= ftol * obj'
+//               or maxiter; fp64 arithmetic on the fp32 Gram entries, like the torch form
+//
+//   cclip       centred clipping in coefficient space (aggregators/centeredclipping.py; reference
+//               blades/aggregators/centeredclipping.py): every iterate is m_t = c0 m_0 + sum_j c_j x_j, so with
+//               G = X X^T, p = X m_0 and |m_0|^2 the distances ||x_i - m_t|| and the update
+//               m <- (1 - S/K) m + (1/K) sum_i s_i x_i, s_i = min(1, tau / ||x_i - m||), need no pass over X
+//
+// All loops have a fixed upper bound; every reduction has a fixed order (bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int KMAX = 128;
+constexpr int TPB = 256;
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+  // fixed-order tree over the 256 threads
+  red[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll
+  for (int s = TPB / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const T r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(TPB) void power_top_kernel(const float* __restrict__ G, int K, int steps, float* __restrict__ out) {
+  extern __shared__ float lds[];
+  float* g = lds;                    // [K][K + 1]
+  float* v = g + K * (K + 1);        // [K]
+  float* red = v + KMAX;             // [TPB]
+  const int t = threadIdx.x;
+  for (int i = t; i < K * K; i += TPB) g[(i / K) * (K + 1) + (i % K)] = G[i];
+  if (t < K) v[t] = 1.0f / sqrtf((float)K) + (float)t * (1e-3f / (float)K);
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    float w = 0.f;
+    if (t < K) {
+      const float* row = g + t * (K + 1);
+      for (int j = 0; j < K; ++j) w += row[j] * v[j];
+    }
+    const float n2 = block_sum<float>(w * w, red);  // (barriers inside: every thread has read v)
+    const float nrm = fmaxf(sqrtf(n2), 1e-30f);
+    if (t < K) v[t] = w / nrm;
+    __syncthreads();
+  }
+  if (t < K) out[t] = v[t];
+}
+
+__global__ __launch_bounds__(TPB) void weiszfeld_kernel(const float* __restrict__ G, const float* __restrict__ w0, int K,
+                                                        int maxiter, double eps, double ftol, float* __restrict__ alpha_out,
+                                                        int* __restrict__ iters_out) {
+  extern __shared__ float lds[];
+  float* g = lds;                                                   // [K][K + 1]
+  double* a = reinterpret_cast<double*>(g + ((K * (K + 1) + 1) & ~1));  // [KMAX] coefficients
+  double* red = a + KMAX;                                           // [TPB]
+  const int t = threadIdx.x;
+  for (int i = t; i < K * K; i += TPB) g[(i / K) * (K + 1) + (i % K)] = G[i];
+  const double wt = t < K ? (double)w0[t] : 0.0;
+  __syncthreads();
+  const double wsum = block_sum<double>(wt, red);
+  const double diag = t < K ? (double)g[t * (K + 1) + t] : 0.0;
+  // dist of the coefficient vector in `a` (every thread gets its own entry; obj = sum_i dist_i w0_i / sum w0)
+  auto dist_of = [&](double& obj) {
+    double ga = 0.0;
+    if (t < K) {
+      const float* row = g + t * (K + 1);
+      for (int j = 0; j < K; ++j) ga += (double)row[j] * a[j];
+    }
+    const double q = block_sum<double>(t < K ? a[t] * ga : 0.0, red);
+    const double d2 = diag - 2.0 * ga + q;
+    const double d = t < K ? sqrt(d2 > 0.0 ? d2 : 0.0) : 0.0;
+    obj = block_sum<double>(d * wt, red) / wsum;
+    return d;
+  };
+  if (t < K) a[t] = wt / wsum;
+  __syncthreads();
+  double obj;
+  double dist = dist_of(obj);
+  int it = 0;
+  for (; it < maxiter; ++it) {
+    const double cw = t < K ? wt / (dist > eps ? dist : eps) : 0.0;
+    const double cs = block_sum<double>(cw, red);
+    if (t < K) a[t] = cw / cs;
+    __syncthreads();
+    double cobj;
+    dist = dist_of(cobj);
+    const bool conv = fabs(obj - cobj) <= ftol * cobj;  // the same value in every thread
+    obj = cobj;
+    if (conv) { ++it; break; }
+  }
+  if (t < K) alpha_out[t] = (float)a[t];
+  if (t == 0) *iters_out = it;
+}
+
+// out[0] = c0, out[1 + j] = c_j (fp64)
+__global__ __launch_bounds__(TPB) void cclip_kernel(const float* __restrict__ G, const float* __restrict__ pvec,
+                                                    const float* __restrict__ mm_ptr, int K, int n_iter, double tau,
+                                                    double* __restrict__ out) {
+  extern __shared__ float lds[];
+  float* g = lds;
+  double* c = reinterpret_cast<double*>(g + ((K * (K + 1) + 1) & ~1));  // [KMAX]
+  double* red = c + KMAX;                                               // [TPB]
+  const int t = threadIdx.x;
+  for (int i = t; i < K * K; i += TPB) g[(i / K) * (K + 1) + (i % K)] = G[i];
+  if (t < K) c[t] = 0.0;
+  __syncthreads();
+  const double diag = t < K ? (double)g[t * (K + 1) + t] : 0.0;
+  const double p = t < K ? (double)pvec[t] : 0.0;
+  const double mm = (double)*mm_ptr;
+  double c0 = 1.0;
+  for (int it = 0; it < n_iter; ++it) {
+    double gc = 0.0;
+    if (t < K) {
+      const float* row = g + t * (K + 1);
+      for (int j = 0; j < K; ++j) gc += (double)row[j] * c[j];
+    }
+    const double cp = block_sum<double>(t < K ? c[t] * p : 0.0, red);
+    const double cgc = block_sum<double>(t < K ? c[t] * gc : 0.0, red);
+    const double m2 = c0 * c0 * mm + 2.0 * c0 * cp + cgc;
+    const double d2 = diag - 2.0 * (c0 * p + gc) + m2;
+    // tau / 0 = inf -> 1, like the tensor form
+    const double sc = t < K ? (d2 > 0.0 ? fmin(1.0, tau / sqrt(d2)) : 1.0) : 0.0;
+    const double S = block_sum<double>(sc, red);
+    const double keep = 1.0 - S / (double)K;
+    if (t < K) c[t] = c[t] * keep + sc / (double)K;
+    c0 *= keep;
+    __syncthreads();
+  }
+  if (t == 0) out[0] = c0;
+  if (t < K) out[1 + t] = c[t];
+}
+
+}  // namespace
+
+// G: [K, K]; p: [K] = X m_0; mm: one float = |m_0|^2 (device); out: 1 + K doubles (c0, c).
+BLADES_API int blades_cclip(const float* G, const float* p, const float* mm, int K, int n_iter, double tau, double* out,
+                            hipStream_t st) {
+  if (K < 1 || K > KMAX || n_iter < 0 || n_iter > 100000 || !(tau > 0.0)) return 1;
+  const size_t gwords = ((size_t)K * (K + 1) + 1) & ~(size_t)1;
+  const size_t lds = gwords * sizeof(float) + (KMAX + TPB) * sizeof(double);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cclip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (KMAX * (KMAX + 1) + 2) * (int)sizeof(float) + (KMAX + TPB) * (int)sizeof(double));
+    attr = true;
+  }
+  hipLaunchKernelGGL(cclip_kernel, dim3(1), dim3(TPB), lds, st, G, p, mm, K, n_iter, tau, out);
+  return 0;
+}
+
+BLADES_API int blades_smallk_max() { return KMAX; }
+
+// G: [K, K] fp32 contiguous, symmetric.  out: [K].  returns 0 ok.
+BLADES_API int blades_power_top(const float* G, int K, int steps, float* out, hipStream_t st) {
+  if (K < 1 || K > KMAX || steps < 1 || steps > 100000) return 1;
+  const size_t lds = ((size_t)K * (K + 1) + KMAX + TPB) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(power_top_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (KMAX * (KMAX + 1) + KMAX + TPB) * (int)sizeof(float));
+    attr = true;
+  }
+  hipLaunchKernelGGL(power_top_kernel, dim3(1), dim3(TPB), lds, st, G, K, steps, out);
+  return 0;
+}
+
+// alpha_out: [K] fp32 coefficients of the geometric median; iters_out: one int (Weiszfeld iterations run).
+BLADES_API int blades_weiszfeld(const float* G, const float* w0, int K, int maxiter, double eps, double ftol,
+                                float* alpha_out, int* iters_out, hipStream_t st) {
+  if (K < 1 || K > KMAX || maxiter < 0 || maxiter > 1000000) return 1;
+  const size_t gwords = ((size_t)K * (K + 1) + 1) & ~(size_t)1;
+  const size_t lds = gwords * sizeof(float) + (KMAX + TPB) * sizeof(double);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(weiszfeld_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (KMAX * (KMAX + 1) + 2) * (int)sizeof(float) + (KMAX + TPB) * (int)sizeof(double));
+    attr = true;
+  }
+  hipLaunchKernelGGL(weiszfeld_kernel, dim3(1), dim3(TPB), lds, st, G, w0, K, maxiter, eps, ftol, alpha_out, iters_out);
+  return 0;
+}

@@ -861,6 +861,56 @@ def test_aggregators_gpu_match_cpu(dev, name, kw):
         torch.testing.assert_close(out_g.cpu(), out_c, rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("K", [5, 60, 128])
+def test_small_client_count_gram_solvers(dev, K):
+    """ops/csrc/smallk.hip: the single-launch power iteration (DnC) and Weiszfeld loop (GeoMed) on a K x K Gram matrix
+    against the library-call forms they replace for K <= 128."""
+    from blades_amd import ops
+    from blades_amd.ops import reference as ref
+
+    h = ops._h()
+    assert h.SMALLK_MAX == 128
+    g = torch.Generator().manual_seed(K)
+    X = torch.randn(K, 300, generator=g)
+    X[: max(1, K // 5)] += 0.7  # an outlier cluster: a clear top direction
+    Xc = X - X.mean(0, keepdim=True)
+    G = (Xc @ Xc.t()).to(dev)
+    v = h.power_top(G, 72)
+    v_ref = ref.power_iteration_top(G.double().cpu(), 8)
+    cos = float((v.double().cpu() * v_ref).sum() / (v.double().cpu().norm() * v_ref.norm()))
+    assert abs(abs(cos) - 1) < 1e-6 and abs(float(v.norm()) - 1) < 1e-5
+    assert torch.equal(v, h.power_top(G, 72))  # fixed-order reductions
+
+    # Weiszfeld: the torch loop of GeoMed._aggregate_gram in fp64 on the CPU
+    Gm = (X @ X.t())
+    w0 = torch.rand(K, generator=g) + 0.5
+    for maxiter, ftol in ((100, 1e-10), (3, 1e-10), (100, 1e-3), (0, 1e-10)):
+        Gd, wd = Gm.float().double(), w0.double()
+        diag = torch.diagonal(Gd)
+
+        def dist_of(al):
+            Ga = Gd @ al
+            return (diag - 2 * Ga + al @ Ga).clamp_min(0).sqrt()
+
+        alpha = wd / wd.sum()
+        dist = dist_of(alpha)
+        obj = (dist * wd).sum() / wd.sum()
+        n = 0
+        for _ in range(maxiter):
+            cw = wd / dist.clamp_min(1e-6)
+            alpha = cw / cw.sum()
+            dist = dist_of(alpha)
+            cobj = (dist * wd).sum() / wd.sum()
+            n += 1
+            conv = bool((obj - cobj).abs() <= ftol * cobj)
+            obj = cobj
+            if conv:
+                break
+        a_gpu, iters = h.weiszfeld(Gm.float().to(dev), w0.to(dev), maxiter, 1e-6, ftol)
+        assert int(iters) == n
+        torch.testing.assert_close(a_gpu.double().cpu(), alpha, rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize("cls_name,kw,agg", [
     ("ALIEAdversary", {}, None), ("ALIEAdversary", {}, "Signguard"), ("IPMAdversary", {"scale": 0.1}, None),
     ("IPMAdversary", {"scale": 100.0}, None), ("NoiseAdversary", {}, None), ("AdaptiveAdversary", {}, None),
