@@ -232,6 +232,10 @@ class _PCConvFn(torch.autograd.Function):
                 w2 = F.pad(wk.reshape(*wk.shape[:-3], Ci * 9), (0, wd - Ci * 9)).reshape(*wk.shape[:-3], wd, 1, 1)
             ctx.stem = True
             ctx.save_for_backward(col, w2)
+            if not want_stats and _hipmod().stem_valu_ok(col, int(weight.shape[-4]), 1 if w2.dim() == 4 else mod.sink.Kc):
+                # single-channel first layer without a BatchNorm behind it (the Fashion-MNIST / MNIST CNN): 512 FMAs
+                # against 192 bytes per pixel — a streaming fp32 kernel on the vector ALUs (ops/csrc/stem_valu.hip)
+                return _hipmod().stem_forward_valu(col, w2, mod.sink.param(mod.bias))
             if want_stats and _BN_STATS_IN_CONV:
                 y, mod.bn_stats = _hipmod().conv_forward(col, w2, mod.sink.param(mod.bias), 1, 0, mod.sink.npl,
                                                          stats_B=x.shape[0] // mod.sink.Kc, planes=planes)
@@ -268,8 +272,11 @@ class _PCConvFn(torch.autograd.Function):
         if ctx.stem:
             off, _ = sink.offsets[id(mod.weight)]
             acc = id(mod.weight) in sink._written
-            ok = _hipmod().conv_wgrad_(x, gy, Kc, sink.block, off, sink.scale, acc, 1, 1, 0, sink.npl,
-                                       cin_store=int(mod.weight.shape[1]) * 9)
+            if _hipmod().stem_valu_ok(x, int(gy.shape[1]), Kc):
+                ok = _hipmod().stem_wgrad_valu_(x, gy, Kc, sink.block, off, sink.scale, acc, int(mod.weight.shape[1]) * 9)
+            else:
+                ok = _hipmod().conv_wgrad_(x, gy, Kc, sink.block, off, sink.scale, acc, 1, 1, 0, sink.npl,
+                                           cin_store=int(mod.weight.shape[1]) * 9)
             if not ok:
                 raise RuntimeError("stem weight gradient: the 1x1 kernel rejected the im2col problem")
             sink._written.add(id(mod.weight))

@@ -1190,6 +1190,76 @@ def stem_im2col(x: torch.Tensor, k: int, pad: int) -> torch.Tensor:
     return out
 
 
+_stem_valu_ok = _opt_sig("blades_stem_valu_ok", [c_long, c_long, c_int, c_int], c_int)
+_stem_fwd_valu = _opt_sig("blades_stem_fwd_valu", [_P, _P, c_long, _P, c_long, _P, c_long, c_long, c_int, _P], c_int)
+_stem_wgrad_nchunk = _opt_sig("blades_stem_wgrad_nchunk", [c_long], c_int)
+_stem_wgrad_valu = _opt_sig("blades_stem_wgrad_valu", [_P, _P, c_int, c_long, c_int, c_int, _P, _P, c_long, c_long, c_int,
+                                                       _P, _P], c_int)
+_STEM_VALU = _os.environ.get("BLADES_STEM_VALU", "1") != "0"
+
+
+def stem_valu_ok(col: torch.Tensor, Co: int, groups: int) -> bool:
+    """Can the vector-ALU first-layer kernels (ops/csrc/stem_valu.hip) take this im2col tensor?  ``groups`` = number of
+    weight sets the rows are divided over (1: shared weights; Kc: per-client weights / per-client gradients)."""
+    if _stem_valu_ok is None or not _STEM_VALU or not (col.is_cuda and col.dtype == torch.float32 and col.dim() == 4):
+        return False
+    N, wd, H, W = col.shape
+    M = N * H * W
+    if groups < 1 or M % groups or not col.is_contiguous(memory_format=torch.channels_last):
+        return False
+    return bool(_stem_valu_ok(M, M // groups, int(wd), int(Co)))
+
+
+def stem_forward_valu(col: torch.Tensor, w2: torch.Tensor, bias) -> torch.Tensor:
+    """``y[n, :, h, w] = w2 col[n, :, h, w] + bias`` in plain fp32 on the vector ALUs.  ``col`` ``[N, 16, H, W]``
+    channels-last; ``w2`` ``[Co, 16, 1, 1]`` (shared) or ``[Kc, Co, 16, 1, 1]`` (image n uses set n // (N / Kc));
+    ``bias`` ``[Co]`` / ``[Kc, Co]`` / None.  Returns ``[N, Co, H, W]`` channels-last."""
+    N, wd, H, W = col.shape
+    M = N * H * W
+    if w2.dim() == 5:
+        Kc, Co = int(w2.shape[0]), int(w2.shape[1])
+        if w2.stride(2) != 1 or w2.stride(1) != wd:
+            w2 = w2.contiguous()
+        w_cs = int(w2.stride(0))
+    else:
+        Kc, Co, w_cs = 1, int(w2.shape[0]), 0
+        w2 = w2.contiguous()
+    b_cs = 0
+    if bias is not None:
+        if bias.dim() == 2:
+            if bias.stride(1) != 1:
+                bias = bias.contiguous()
+            b_cs = int(bias.stride(0))
+        elif not bias.is_contiguous():
+            bias = bias.contiguous()
+    out = _empty((N, Co, H, W), dtype=torch.float32, device=col.device, memory_format=torch.channels_last)
+    rc = _stem_fwd_valu(_ptr(col), _ptr(w2), w_cs, _ptr(bias) if bias is not None else None, b_cs, _ptr(out), M, M // Kc, Co,
+                        _stream())
+    if rc != 0:
+        raise ValueError(f"stem_forward_valu: rejected (rc={rc})")
+    return out
+
+
+def stem_wgrad_valu_(col, gy, Kc: int, U_block, off: int, coef, accumulate: bool, kreal: int) -> bool:
+    """``U_block[c, off + o * kreal + k] (+)= coef[c] * sum over client c's pixels of gy[., o] * col[., k]`` (k < kreal),
+    plain fp32.  ``col`` ``[N, 16, H, W]``, ``gy`` ``[N, Co, H, W]``, both channels-last fp32."""
+    N, wd, H, W = col.shape
+    Co = int(gy.shape[1])
+    if not gy.is_contiguous(memory_format=torch.channels_last):
+        gy = gy.contiguous(memory_format=torch.channels_last)
+    K, Dl, ld = _chk_matrix(U_block)
+    if K != Kc or off < 0 or off + Co * kreal > Dl:
+        raise ValueError("stem_wgrad_valu_: update-matrix block does not match")
+    R = N * H * W // Kc
+    coef = _vec(coef, Kc, col.device, name="coef")
+    partial = _empty(Kc * int(_stem_wgrad_nchunk(R)) * Co * wd, device=col.device)
+    rc = _stem_wgrad_valu(_ptr(col), _ptr(gy), Kc, R, Co, int(kreal), _ptr(coef), _ptr(U_block), ld, off, int(accumulate),
+                          _ptr(partial), _stream())
+    if rc != 0:
+        raise ValueError(f"stem_wgrad_valu_: rejected (rc={rc})")
+    return True
+
+
 _im2col_c = _opt_sig("blades_im2col", [_P, _P, c_long] + [c_int] * 13 + [_P], c_int)
 
 

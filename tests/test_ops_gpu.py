@@ -1449,6 +1449,56 @@ def test_conv_epilogue_statistics_decline_straddling_tiles(dev):
     torch.testing.assert_close(y, torch.nn.functional.conv2d(x, w, None, 1, 1), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("Co,B,HW", [(32, 4, 28), (16, 8, 16), (8, 64, 28)])
+def test_single_channel_stem_on_vector_alus(dev, Co, B, HW):
+    """ops/csrc/stem_valu.hip: the single-channel 3x3 first layer (im2col, 16 columns) as plain-fp32 streaming kernels —
+    forward with shared and with per-client weights, per-client weight gradient into the update rows — against fp64."""
+    import torch.nn.functional as F
+    from blades_amd.engine.fused import _stem_im2col
+    from blades_amd.ops import _hip as h
+
+    torch.manual_seed(Co + B)
+    Kc = 3
+    x = torch.randn(Kc * B, 1, HW, HW, device=dev)
+    x = x.as_strided(x.shape, (x.stride(0), 1, x.stride(2), x.stride(3)))
+    col = _stem_im2col(x, 3, 1)
+    assert h.stem_valu_ok(col, Co, 1) and h.stem_valu_ok(col, Co, Kc)
+    w = torch.randn(Kc, Co, 1, 3, 3, device=dev) / 3
+    b = torch.randn(Kc, Co, device=dev)
+    w2 = F.pad(w.reshape(Kc, Co, 9), (0, 7)).reshape(Kc, Co, 16, 1, 1)
+    # shared weights
+    y = h.stem_forward_valu(col, w2[0], b[0])
+    assert y.shape == (Kc * B, Co, HW, HW) and y.is_contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x.double(), w[0].double(), b[0].double(), 1, 1)
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
+    # per-client weights taken as rows of a wider matrix
+    Wm = torch.randn(Kc, Co * 16 + Co + 8, device=dev)
+    wv = Wm.as_strided((Kc, Co, 16, 1, 1), (Wm.stride(0), 16, 1, 1, 1), 0)
+    bv = Wm.as_strided((Kc, Co), (Wm.stride(0), 1), Co * 16)
+    y = h.stem_forward_valu(col, wv, bv)
+    for c in range(Kc):
+        wc = Wm[c, : Co * 16].reshape(Co, 16)[:, :9].reshape(Co, 1, 3, 3).double()
+        ref = F.conv2d(x[c * B:(c + 1) * B].double(), wc, bv[c].double(), 1, 1)
+        torch.testing.assert_close(y[c * B:(c + 1) * B].double(), ref, rtol=1e-5, atol=1e-5)
+    # weight gradient
+    gy = torch.randn(Kc * B, Co, HW, HW, device=dev).contiguous(memory_format=torch.channels_last)
+    U = torch.full((Kc, Co * 9 + 9), 7.0, device=dev)
+    coef = torch.tensor([1.0, -0.5, 2.0], device=dev)
+    assert h.stem_wgrad_valu_(col, gy, Kc, U, 4, coef, False, 9)
+    ref = torch.stack([torch.ops.aten.convolution_backward(
+        gy[c * B:(c + 1) * B].double(), x[c * B:(c + 1) * B].double().contiguous(), w[c].double(), None, [1, 1], [1, 1],
+        [1, 1], False, [0, 0], 1, [False, True, False])[1] * coef[c].double() for c in range(Kc)])
+    got = U[:, 4:4 + Co * 9].reshape(Kc, Co, 1, 3, 3).double()
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert float((U[:, :4] - 7).abs().max()) == 0 and float((U[:, 4 + Co * 9:] - 7).abs().max()) == 0
+    U2 = U.clone()
+    assert h.stem_wgrad_valu_(col, gy, Kc, U2, 4, coef, True, 9)
+    torch.testing.assert_close(U2[:, 4:4 + Co * 9], 2 * U[:, 4:4 + Co * 9], rtol=1e-6, atol=1e-6)
+    U3 = torch.full((Kc, Co * 9 + 9), 7.0, device=dev)
+    h.stem_wgrad_valu_(col, gy, Kc, U3, 4, coef, False, 9)
+    assert torch.equal(U3, U)  # fixed-order reductions
+
+
 @pytest.mark.parametrize("npl", [3, 2])
 @pytest.mark.parametrize("Ci,Co,HW", [(3, 64, 32), (1, 32, 28)])
 def test_stem_as_im2col_pointwise_convolution(dev, npl, Ci, Co, HW):
