@@ -1218,7 +1218,7 @@ def stem_forward_valu(col: torch.Tensor, w2: torch.Tensor, bias) -> torch.Tensor
     M = N * H * W
     if w2.dim() == 5:
         Kc, Co = int(w2.shape[0]), int(w2.shape[1])
-        if w2.stride(2) != 1 or w2.stride(1) != wd:
+        if w2.stride(2) != 1 or w2.stride(1) != wd or w2.stride(0) % 4 or w2.data_ptr() % 16:
             w2 = w2.contiguous()
         w_cs = int(w2.stride(0))
     else:
