@@ -1379,6 +1379,7 @@ def test_conv_epilogue_batchnorm_statistics(dev, Kc, B, Ci, HW, Co, k, s, p):
     (2, 16, 256, 8, 256, 3, 1, 1, False, False),  # four images per tile, BatchNorm without ReLU
     (2, 16, 512, 4, 512, 3, 1, 1, True, True),   # sixteen images per tile (register-fed weight path)
     (2, 8, 128, 16, 256, 3, 2, 1, False, True),
+    (3, 4, 64, 32, 128, 3, 2, 1, True, True),    # first convolution of a down-sampling block adding onto the shortcut's gradient
 ])
 @pytest.mark.parametrize("path", ["default", "rf", "lds-mf2"])
 def test_conv_dgrad_epilogue_batchnorm_backward_sums(dev, monkeypatch, Kc, B, Ci, HW, Co, k, s, p, acc, gate, path):
