@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from blades_amd.ops.activations import gelu
+from blades_amd.ops.activations import gelu, seq_pool
 
 
 class DropPath(nn.Module):
@@ -151,7 +151,7 @@ class TransformerClassifier(nn.Module):
             x = blk(x)
         x = self.norm(x)
         if self.seq_pool:
-            x = torch.matmul(F.softmax(self.attention_pool(x), dim=1).transpose(-1, -2), x).squeeze(-2)
+            x = seq_pool(x, self.attention_pool(x))
         else:
             x = x[:, 0]
         return self.fc(x)

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from blades_amd.ops.activations import gelu
+from blades_amd.ops.activations import gelu, seq_pool
 
 from .layers import DropPath, sinusoidal_embedding
 
@@ -170,7 +170,7 @@ class MaskedTransformerClassifier(nn.Module):
             logit = self.attention_pool(x)
             if mask is not None:
                 logit = logit.masked_fill(~mask.unsqueeze(-1), -torch.finfo(logit.dtype).max)
-            x = torch.matmul(F.softmax(logit, dim=1).transpose(-1, -2), x).squeeze(-2)
+            x = seq_pool(x, logit)
         else:
             x = x[:, 0]
         return self.fc(x)

@@ -1613,6 +1613,40 @@ def ce_clamp(logits, labels, lo: float, hi: float, want_grad: bool = True):
     return loss, dz
 
 
+_seqpool_fwd = _opt_sig("blades_seqpool_forward", [_P, _P, _P, _P, c_long, c_int, c_int, _P], c_int)
+_seqpool_bwd = _opt_sig("blades_seqpool_backward", [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P], c_int)
+
+
+def seqpool_supported(x, logit) -> bool:
+    return (_seqpool_fwd is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
+            and logit.dtype == torch.float32 and logit.numel() == x.shape[0] * x.shape[1] and 1 <= x.shape[1] <= 1024)
+
+
+def seqpool_forward(x, logit):
+    """``y[b] = softmax_t(logit[b])^T x[b]`` for ``x [B, T, C]``, ``logit [B, T]`` (or ``[B, T, 1]``): (y [B, C], p [B, T])."""
+    B, T, C = (int(v) for v in x.shape)
+    x = x if x.is_contiguous() else x.contiguous()
+    lg = logit.reshape(B, T)
+    lg = lg if lg.is_contiguous() else lg.contiguous()
+    y = _empty((B, C), device=x.device)
+    p = _empty((B, T), device=x.device)
+    if _seqpool_fwd(_ptr(x), _ptr(lg), _ptr(y), _ptr(p), B, T, C, _stream()) != 0:
+        raise ValueError("seqpool_forward: rejected")
+    return y, p
+
+
+def seqpool_backward(x, p, gy):
+    """Gradients of ``seqpool_forward``: (dx [B, T, C], dlogit [B, T])."""
+    B, T, C = (int(v) for v in x.shape)
+    x = x if x.is_contiguous() else x.contiguous()
+    gy = gy if gy.is_contiguous() else gy.contiguous()
+    dx = _empty((B, T, C), device=x.device)
+    dl = _empty((B, T), device=x.device)
+    if _seqpool_bwd(_ptr(x), _ptr(p), _ptr(gy), _ptr(dx), _ptr(dl), B, T, C, _stream()) != 0:
+        raise ValueError("seqpool_backward: rejected")
+    return dx, dl
+
+
 # ---------------------------------------------------------------------------
 # fused evaluation metrics
 _ce_topk = _sig("blades_ce_topk", [_P, c_long, _P, c_long, c_int, _P, c_int, _P, c_int, _P, _P], c_int)

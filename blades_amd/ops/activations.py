@@ -55,3 +55,35 @@ def gelu(x: torch.Tensor) -> torch.Tensor:
 
 def relu(x: torch.Tensor) -> torch.Tensor:
     return _ActFn.apply(x, 1) if _hip_ok(x) else F.relu(x)
+
+
+class _SeqPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, logit):
+        from blades_amd import ops
+
+        y, p = ops._h().seqpool_forward(x, logit)
+        ctx.save_for_backward(x, p)
+        ctx.lshape = logit.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from blades_amd import ops
+
+        x, p = ctx.saved_tensors
+        dx, dl = ops._h().seqpool_backward(x, p, gy)
+        return dx, dl.reshape(ctx.lshape)
+
+
+def seq_pool(x: torch.Tensor, logit: torch.Tensor) -> torch.Tensor:
+    """Sequence pooling of the compact transformers: ``softmax(logit, dim=tokens)^T x`` for ``x [B, T, C]`` and
+    ``logit [B, T, 1]`` -> ``[B, C]`` (reference: fllib/models/backbones/cctnets/utils/transformers.py, the
+    ``attention_pool`` branch).  Inside the fused executor on the GPU: one kernel forward, one backward
+    (ops/csrc/elementwise.hip) instead of softmax + transpose + a batched library GEMM and their backward kernels."""
+    if _depth > 0 and x.is_cuda and x.dtype == torch.float32 and logit.dtype == torch.float32 and x.dim() == 3:
+        from blades_amd import ops
+
+        if ops._h().seqpool_supported(x, logit):
+            return _SeqPoolFn.apply(x, logit)
+    return torch.matmul(F.softmax(logit, dim=1).transpose(-1, -2), x).squeeze(-2)

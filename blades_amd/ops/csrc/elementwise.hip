@@ -383,6 +383,73 @@ inline int grid_for(long n, int cap = 4096) {
   return (int)(g > cap ? cap : g);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// sequence pooling of the compact transformers (reference fllib/models/backbones/cctnets/utils/transformers.py:
+// softmax(attention_pool(x), dim = tokens)^T x):  y[b, c] = sum_t p[b, t] x[b, t, c],  p = softmax_t(logit[b, .]).
+// One workgroup per sample.  Backward: dp_t = gy . x[t], dlogit_t = p_t (dp_t - sum_u p_u dp_u), dx[t, c] = p_t gy[c].
+constexpr int SP_TMAX = 1024;
+
+__global__ __launch_bounds__(TPB) void seqpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ logit,
+                                                          float* __restrict__ y, float* __restrict__ p, int T, int C) {
+  __shared__ float pt[SP_TMAX];
+  __shared__ float red[4];
+  const long b = blockIdx.x;
+  const int t = threadIdx.x;
+  const float* lg = logit + b * T;
+  float m = -INFINITY;
+  for (int i = t; i < T; i += TPB) m = fmaxf(m, lg[i]);
+  m = wave_max(m);
+  if ((t & 63) == 0) red[t >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int i = t; i < T; i += TPB) {
+    const float e = __expf(lg[i] - m);
+    pt[i] = e;
+    s += e;
+  }
+  s = block_sum_256(s, red);
+  const float inv = 1.f / s;
+  for (int i = t; i < T; i += TPB) {
+    const float v = pt[i] * inv;
+    pt[i] = v;
+    p[b * T + i] = v;
+  }
+  __syncthreads();
+  const float* xb = x + b * (long)T * C;
+  for (int c = t; c < C; c += TPB) {
+    float a = 0.f;
+    for (int i = 0; i < T; ++i) a = fmaf(pt[i], xb[(long)i * C + c], a);
+    y[b * C + c] = a;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void seqpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ p,
+                                                          const float* __restrict__ gy, float* __restrict__ dx,
+                                                          float* __restrict__ dlogit, int T, int C) {
+  __shared__ float dp[SP_TMAX];
+  __shared__ float red[4];
+  const long b = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* xb = x + b * (long)T * C;
+  const float* g = gy + b * C;
+  const float* pb = p + b * T;
+  for (int i = wave; i < T; i += 4) {  // a wave per token: dp_i = gy . x[i]
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(g[c], xb[(long)i * C + c], a);
+    a = wave_sum(a);
+    if (lane == 0) dp[i] = a;
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int i = t; i < T; i += TPB) s += pb[i] * dp[i];
+  s = block_sum_256(s, red);
+  for (int i = t; i < T; i += TPB) dlogit[b * T + i] = pb[i] * (dp[i] - s);
+  float* db = dx + b * (long)T * C;
+  const long n = (long)T * C;
+  for (long e = t; e < n; e += TPB) db[e] = pb[e / C] * g[e % C];
+}
+
 }  // namespace
 
 // rows of one client per stage-1 block
@@ -530,5 +597,20 @@ BLADES_API int blades_ce_clamp(const float* z, long ld, const long* labels, int 
                                const float* gl, float* loss, float* dz, hipStream_t st) {
   if (Kc <= 0 || B <= 0 || C <= 0 || ld < C) return 1;
   hipLaunchKernelGGL(ce_clamp_kernel, dim3(Kc), dim3(TPB), 0, st, z, ld, labels, B, C, lo, hi, gl, loss, dz);
+  return 0;
+}
+
+// x [B, T, C], logit [B, T] -> y [B, C], p [B, T] (the softmax weights, kept for the backward pass).  fp32.
+BLADES_API int blades_seqpool_forward(const float* x, const float* logit, float* y, float* p, long B, int T, int C,
+                                      hipStream_t st) {
+  if (B <= 0 || B > 0x7fffffffL || T < 1 || T > SP_TMAX || C < 1) return 1;
+  hipLaunchKernelGGL(seqpool_fwd_kernel, dim3((unsigned)B), dim3(TPB), 0, st, x, logit, y, p, T, C);
+  return 0;
+}
+
+BLADES_API int blades_seqpool_backward(const float* x, const float* p, const float* gy, float* dx, float* dlogit, long B, int T,
+                                       int C, hipStream_t st) {
+  if (B <= 0 || B > 0x7fffffffL || T < 1 || T > SP_TMAX || C < 1) return 1;
+  hipLaunchKernelGGL(seqpool_bwd_kernel, dim3((unsigned)B), dim3(TPB), 0, st, x, p, gy, dx, dlogit, T, C);
   return 0;
 }

@@ -681,6 +681,31 @@ def test_maxpool_kernels(dev, N, C, H, W, k, s, p, relu, dt):
     torch.testing.assert_close(dx.float().cpu(), dxr, rtol=tol, atol=tol * float(gy.float().abs().max()) * k * k)
 
 
+@pytest.mark.parametrize("B,T,C", [(37, 64, 128), (5, 65, 130), (3, 1, 8), (2, 300, 384), (4, 1024, 16)])
+def test_sequence_pooling_kernels(dev, B, T, C):
+    """softmax(logit over tokens)^T x of the compact transformers' classifier head, forward and backward, against fp64."""
+    from blades_amd.ops import _hip as h
+
+    g = torch.Generator().manual_seed(B * T + C)
+    x = torch.randn(B, T, C, generator=g)
+    lg = torch.randn(B, T, 1, generator=g) * 3
+    gy = torch.randn(B, C, generator=g)
+    xr, lr = x.double().requires_grad_(True), lg.double().requires_grad_(True)
+    yr = torch.matmul(torch.softmax(lr, dim=1).transpose(-1, -2), xr).squeeze(-2)
+    dxr, dlr = torch.autograd.grad(yr, (xr, lr), gy.double())
+    xd, ld = x.to(dev), lg.to(dev)
+    assert h.seqpool_supported(xd, ld)
+    y, p = h.seqpool_forward(xd, ld)
+    torch.testing.assert_close(y.double().cpu(), yr.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(p.double().cpu(), torch.softmax(lg.double(), dim=1).squeeze(-1), rtol=1e-5, atol=1e-7)
+    dx, dl = h.seqpool_backward(xd, p, gy.to(dev))
+    torch.testing.assert_close(dx.double().cpu(), dxr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dl.double().cpu(), dlr.squeeze(-1), rtol=1e-4, atol=1e-5)
+    y2, p2 = h.seqpool_forward(xd, ld)
+    dx2, dl2 = h.seqpool_backward(xd, p, gy.to(dev))
+    assert torch.equal(y2, y) and torch.equal(p2, p) and torch.equal(dx2, dx) and torch.equal(dl2, dl)
+
+
 @pytest.mark.parametrize("shape", [(1000, 128), (64, 49, 128), (7, 13), (4096, 600), (3, 5, 7, 11)])
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
