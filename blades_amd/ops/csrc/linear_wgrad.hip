@@ -14,7 +14,8 @@
 //   workgroup = (client, 64 inputs i, 64 outputs o), wave w owns inputs [16w, 16w+16) x all 64 outputs;
 //   x is the A operand so a lane ends up with 4 consecutive i of one output row (16-byte stores when aligned).
 // The reduction is short (R = 64 for the headline batch), so the kernel is bound by writing the K x Out x In fp32
-// result once; staging is a plain load -> split -> LDS write -> barrier sequence.
+// result once; with many rows per client (token layers of the compact transformers: R = 4096) the next step's loads
+// are in flight while the current step is multiplied.
 #include "common.h"
 #include <type_traits>
 
@@ -73,9 +74,12 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const LinParams p) {
   const int chunk = tid & 7, row = tid >> 3;
   constexpr int VEC = NPL == 1 ? 8 : 4;  // elements per 16-byte load
   const bool x_vec = (p.In % VEC) == 0, g_vec = (p.Out % VEC) == 0;
-  auto stage = [&](const elem_t* base, int C, int ch0, bool vec, int r, unsigned char* dst) {
-    // 8 channels ch0 .. ch0+7 of row r -> every plane's [block][row][16 ch] image
-    u32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+  // a step's operands: fetched into registers one step ahead of the MFMAs that use them, split and written to LDS
+  // when their turn comes (the reduction of a transformer layer is 4096 rows = 128 steps: without the look-ahead
+  // every step waited for its own loads)
+  auto fetch = [&](const elem_t* base, int C, int ch0, bool vec, int r, u32x4& lo, u32x4& hi) {
+    lo = u32x4{0, 0, 0, 0};
+    hi = u32x4{0, 0, 0, 0};
     if (r < p.R && ch0 < C) {
       const elem_t* src = base + (size_t)r * C + ch0;
       if constexpr (NPL == 1) {
@@ -100,6 +104,9 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const LinParams p) {
         }
       }
     }
+  };
+  auto commit = [&](const u32x4 lo, const u32x4 hi, unsigned char* dst) {
+    // 8 channels of row `row` -> every plane's [block][row][16 ch] image
     unsigned char* d = dst + (chunk >> 1) * 1024 + row * 32 + (chunk & 1) * 16;
     if constexpr (NPL == 1) {
       *reinterpret_cast<u32x4*>(d) = lo;
@@ -117,11 +124,18 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const LinParams p) {
   const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
   const int frag = lq * 32 + lp * 8;  // this lane's address inside a 4-row quad of a [32][16] image
 
+  u32x4 xlo, xhi, glo, ghi;
+  fetch(xc, p.In, i0 + chunk * 8, x_vec, row, xlo, xhi);
+  fetch(gc, p.Out, o0 + chunk * 8, g_vec, row, glo, ghi);
   for (int r0 = 0; r0 < p.R; r0 += 32) {
     __syncthreads();  // previous step's fragments are read
-    stage(xc, p.In, i0 + chunk * 8, x_vec, r0 + row, x_lds);
-    stage(gc, p.Out, o0 + chunk * 8, g_vec, r0 + row, g_lds);
+    commit(xlo, xhi, x_lds);
+    commit(glo, ghi, g_lds);
     __syncthreads();
+    if (r0 + 32 < p.R) {
+      fetch(xc, p.In, i0 + chunk * 8, x_vec, r0 + 32 + row, xlo, xhi);
+      fetch(gc, p.Out, o0 + chunk * 8, g_vec, r0 + 32 + row, glo, ghi);
+    }
     i32x4 a[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
