@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int NPL>
-__global__ __launch_bounds__(256) void mha_bwd_kernel(const MhaParams p) {
+__global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaParams p) {
   using T = std::conditional_t<NPL == 1, unsigned short, float>;
   __shared__ __attribute__((aligned(16))) unsigned char sDO[NPL * IMG];
   __shared__ __attribute__((aligned(16))) unsigned char sQ[NPL * IMG];
