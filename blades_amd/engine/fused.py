@@ -30,6 +30,21 @@ import torch.nn.functional as F
 from torch import nn
 
 
+class _WrittenSet(set):
+    """ids of the parameters whose columns of the sink's block already hold a gradient (a kernel writing such a
+    parameter accumulates instead of overwriting).  ``always``: every parameter counts as written — every kernel then
+    ADDS its scaled result onto what the columns hold, which turns a sink pointed at the clients' weight rows with
+    coefficients ``-lr * gscale`` into the SGD step itself (``FusedFedSGD.run_per_client(step_coef=...)``)."""
+
+    always = False
+
+    def __contains__(self, k):
+        return self.always or set.__contains__(self, k)
+
+    def has(self, k) -> bool:
+        return set.__contains__(self, k)
+
+
 class GradSink:
     """Routes per-client parameter gradients into rows of the update matrix."""
 
@@ -39,7 +54,7 @@ class GradSink:
         self.Kc = 0
         self.B = 0
         self.offsets: Dict[int, tuple] = {}  # id(param) -> (offset, numel)
-        self._written = set()
+        self._written = _WrittenSet()
         # operand planes of the hand-written convolution kernels (ops/csrc/conv_igemm.hip, conv_wgrad.hip):
         # 3 = fp32 activations, exact 3 x bf16 split (fp32 grade); 2 = fp32 activations, "bf16x3"; 1 = bf16
         self.npl = 3
@@ -52,7 +67,7 @@ class GradSink:
 
     def begin(self, block, scale, Kc, B):
         self.block, self.scale, self.Kc, self.B = block, scale, Kc, B
-        self._written = set()
+        self._written = _WrittenSet()
 
     def param(self, p):
         """The tensor a layer computes with: the shared parameter, or its per-client view ``[Kc, *p.shape]`` into
@@ -1090,6 +1105,12 @@ class FusedFedSGD:
         self.amp_dtype = amp_dtype
         self.device = device
         self.sink.npl = 1 if amp_dtype == torch.bfloat16 else (2 if conv_planes == 2 else 3)
+        # In-place client SGD step (run_per_client(step_coef=...)): only for templates without normalisation layers —
+        # the BatchNorm / LayerNorm backward kernels write the affine gradients before their apply pass has read the
+        # affine weights — i.e. the MLP and the CNN, where the separate step is 7 % of a local step.
+        self.inplace_step_ok = (_os.environ.get("BLADES_INPLACE_CLIENT_STEP", "1") != "0" and not any(
+            isinstance(m, (PCBatchNorm2d, PCLayerNorm)) for m in self.template.modules()))
+        self.pc_steps_ok = 0  # completed run_per_client calls (the in-place step is taken after a first regular one)
         from blades_amd.tasks.mnist import MNIST
 
         self._stock_loss = (getattr(type(task), "loss", None) is MNIST.loss
@@ -1141,14 +1162,23 @@ class FusedFedSGD:
         return losses.detach()
 
 
-    def run_per_client(self, W: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
+    def run_per_client(self, W: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, G: Optional[torch.Tensor],
+                       step_coef: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One local step with *per-client* weights (several batches per round, reference
         fllib/clients/client.py:55-61): row c of ``W`` holds client c's flat parameters; the per-client gradients
         go, unscaled, into ``G[Kc, D]``.  Same kernels as the shared-weight path — the convolution and batch-norm
         kernels pick a client's weight set by image index, Linear layers run as one strided-batched GEMM."""
         Kc, B = Y.shape
-        ones = torch.ones(Kc, device=W.device, dtype=torch.float32)
-        self.sink.begin(G, ones, Kc, B)
+        if step_coef is not None:
+            # plain SGD without momentum / clipping on a model whose backward pass reads every weight before it
+            # writes that weight's gradient: the gradient kernels' epilogues add ``step_coef[c] * dW_c`` (= -lr *
+            # gscale * dW) straight onto the weight rows — no gradient matrix, no separate pass over W and G
+            assert self.inplace_step_ok
+            self.sink.begin(W, step_coef, Kc, B)
+            self.sink._written.always = True
+        else:
+            ones = torch.ones(Kc, device=W.device, dtype=torch.float32)
+            self.sink.begin(G, ones, Kc, B)
         self.sink.W = W
         try:
             x = X.reshape(Kc * B, *X.shape[2:])
@@ -1162,9 +1192,10 @@ class FusedFedSGD:
             with torch.enable_grad(), fused_scope():
                 logits = self.template(x)
                 losses = self._loss_backward(logits, Y, Kc, B)
-            missing = [k for k in self.sink.offsets if k not in self.sink._written]
+            missing = [k for k in self.sink.offsets if not self.sink._written.has(k)]
             if missing:
                 raise NotImplementedError(f"{len(missing)} parameters received no per-client gradient")
+            self.pc_steps_ok += 1
             return losses
         finally:
             self.sink.W = None

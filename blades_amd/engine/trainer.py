@@ -541,7 +541,9 @@ class ClientEngine:
             dev_rows = self.sampler.rows_on_device(srows)
             store = self.train_store
             W = torch.empty(Kc, self.D, device=self.device)
-            G = torch.empty_like(W)
+            inplace = self._inplace_client_step()
+            G = None if inplace else torch.empty_like(W)
+            step_coef = (gscale0 * (-self.lr)).contiguous() if inplace else None
             Mv = torch.zeros_like(W) if self.momentum != 0.0 else W
             loss_acc = torch.zeros(Kc, device=self.device)
             params = torch.zeros(Kc, 9, device=self.device) if aug else None
@@ -557,8 +559,11 @@ class ClientEngine:
                     X = tf.apply(X, params)
                 if any_flip:
                     Y = torch.where(flip.unsqueeze(1) > 0, flip.unsqueeze(1) - 1 - Y, Y)
-                losses = self.fused.run_per_client(W, X, Y, G)
-                ops.client_sgd_step_(W, G, Mv, self.lr, self.momentum, False, gscale0)
+                if inplace:
+                    losses = self.fused.run_per_client(W, X, Y, None, step_coef=step_coef)
+                else:
+                    losses = self.fused.run_per_client(W, X, Y, G)
+                    ops.client_sgd_step_(W, G, Mv, self.lr, self.momentum, False, gscale0)
                 loss_acc.add_(losses)
 
             g = torch.cuda.CUDAGraph()
@@ -572,7 +577,7 @@ class ClientEngine:
                 torch.cuda.synchronize()
                 return None
             ent.update(graph=g, W=W, G=G, Mv=Mv, loss=loss_acc, params=params,
-                       keep=(flip, gscale0, dev_rows, uids_t))
+                       keep=(flip, gscale0, dev_rows, uids_t, step_coef))
         W, Mv, loss_acc = ent["W"], ent["Mv"], ent["loss"]
         W.copy_(theta.unsqueeze(0).expand(Kc, -1))
         loss_acc.zero_()
@@ -597,6 +602,13 @@ class ClientEngine:
         self.U_row[rows_t, : self.D] = W - theta.unsqueeze(0)
         return loss_acc / self.nb
 
+    def _inplace_client_step(self) -> bool:
+        """Plain client SGD (no momentum, no gradient clipping) on the fused per-client executor of a model without
+        normalisation layers: the gradient kernels add ``-lr * gscale * dW`` onto the weight rows themselves
+        (engine/fused.py::run_per_client(step_coef=...)); taken once a regular step has gone through."""
+        return (self.fused_pc and self.fused is not None and self.momentum == 0.0 and not self._any_clip
+                and self.fused.inplace_step_ok and self.fused.pc_steps_ok > 0)
+
     def _train_chunk_general(self, theta, rows, srows):
         if self._general_graphs_wanted() and self._mom_init:
             losses = self._graphed_local_steps(theta, rows, srows)
@@ -605,7 +617,9 @@ class ClientEngine:
         gscale0, flip, gclip = self._row_vectors(rows)
         Kc = len(rows)
         W = theta.unsqueeze(0).repeat(Kc, 1)  # a real copy even for Kc == 1 (expand().contiguous() would alias theta)
-        G = torch.empty_like(W)
+        inplace = self._inplace_client_step()
+        G = None if inplace else torch.empty_like(W)
+        step_coef = (gscale0 * (-self.lr)).contiguous() if inplace else None
         srows_t = torch.as_tensor(srows, device=self.device)
         if self.momentum != 0.0:
             if self.M is None:
@@ -624,10 +638,16 @@ class ClientEngine:
             if self.fused_pc:
                 try:
                     self.drop_ctx.set(uids_t, "major")
+                    if inplace:
+                        losses = self.fused.run_per_client(W, X, Y, None, step_coef=step_coef)
+                        loss_acc += losses
+                        continue  # the gradient kernels have taken the SGD step
                     losses = self.fused.run_per_client(W, X, Y, G)
                 except NotImplementedError as e:
                     self.fused_pc, self.fused_pc_error = False, str(e)
                     self._ensure_grouped()
+                    if G is None:
+                        inplace, G = False, torch.empty_like(W)
             if losses is not None:
                 pass
             elif self.grouped is not None:

@@ -86,6 +86,26 @@ def test_graphed_local_steps_match_eager(tmp_path, ds, model, momentum, chunk):
         assert torch.equal(th_g, th_e)
 
 
+@pytest.mark.parametrize("ds,model", [("fashionmnist", "cnn"), ("mnist", "mlp")])
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_inplace_client_step_matches_separate_step(tmp_path, monkeypatch, ds, model, graph):
+    """Plain client SGD on the models without normalisation layers: the gradient kernels add -lr * gscale * dW onto
+    the weight rows themselves (no gradient matrix, no client_sgd pass).  Must match the separate step up to the
+    rounding of one product per element ((lr * gs) * g against lr * (g * gs)), eager and graph-replayed."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    kw = dict(rounds=5, nb=3, momentum=0.0, lr=0.05, chunk="auto")
+    monkeypatch.setenv("BLADES_INPLACE_CLIENT_STEP", "0")
+    th_s, loss_s, eng_s = _run(tmp_path, graph, ds, model, "ALIEAdversary", **kw)
+    monkeypatch.setenv("BLADES_INPLACE_CLIENT_STEP", "1")
+    th_i, loss_i, eng_i = _run(tmp_path, graph, ds, model, "ALIEAdversary", **kw)
+    assert not eng_s.fused.inplace_step_ok and eng_i.fused.inplace_step_ok and eng_i._inplace_client_step()
+    assert eng_i.fused_pc and eng_s.fused_pc
+    assert torch.isfinite(th_i).all()
+    assert max(abs(a - b) for a, b in zip(loss_i, loss_s)) < 1e-4, (loss_i, loss_s)
+    torch.testing.assert_close(th_i, th_s, rtol=1e-4, atol=2e-6)
+
+
 def test_auto_mode_picks_graphs_only_for_small_rounds(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
