@@ -158,10 +158,12 @@ class ClientEngine:
             self.U_row = self._U_store[:, : self.Dpad]
             self.U_col = self.U_row if not self.ctx.distributed else torch.zeros(
                 self.K, self.Dl, dtype=torch.float32, device=self.device)
-        # Client chunks alternate over HIP streams so that one chunk's bandwidth-bound kernels (per-client BN,
-        # elementwise) overlap another chunk's MFMA-bound convolutions: +3 % on the headline round with two
-        # streams, another 1 % with three (four are slower; profiles/r2_chunk_stream_sweep_v6.txt).  Multi-GPU
-        # runs do the same; their exchange pieces are issued one chunk behind (train_round).
+        # Client chunks alternate over HIP streams: +3 % on the headline round with two streams, another 1 % with
+        # three (four are slower; profiles/r2_chunk_stream_sweep_v6.txt).  What the streams buy is closed launch
+        # gaps and tails — a kernel's last, partly filled wave of workgroups runs beside the next chunk's kernel —
+        # not bandwidth-bound kernels hidden under matrix-core ones: a convolution launch fills every CU, and the
+        # serial kernel sum of a round equals its wall clock (profiles/r3_stream_overlap_probe_bn_under_conv.log).
+        # Multi-GPU runs do the same; their exchange pieces are issued one chunk behind (train_round).
         default_streams = "3" if self.device.type == "cuda" else "1"
         self.n_streams = max(1, int(os.environ.get("BLADES_CHUNK_STREAMS", default_streams)))
         # HIP-graph capture of a FedSGD chunk (see _graphed_chunk): "auto" turns it on for launch-bound rounds
@@ -716,8 +718,7 @@ class ClientEngine:
             # theta does not change until the server step: the convolution weights are split into their operand
             # planes once, here, instead of once per chunk and launch
             self.fused.begin_round()
-        # Optional: chunks alternate between `n_streams` HIP streams so that one chunk's memory-bound kernels
-        # (per-client BN, elementwise) can overlap another chunk's MFMA-bound convolutions.
+        # Chunks alternate between `n_streams` HIP streams (closes launch gaps and kernel tails, see __init__).
         n_streams = self.n_streams if (dev.type == "cuda" and not late) else 1
         if n_streams > 1 and self._graphs_wanted():
             n_streams = 1  # launch-bound rounds gain nothing from a second stream; keep replays in sequence
