@@ -83,6 +83,10 @@ class MinMaxAdversary(Adversary):
         high = torch.full((), 5.0, device=U.device)
         mid = (low + high) / 2
         lo_f, hi_f = 0.0, 5.0
+        if U.is_cuda and ops.smallk_max(U.device) > 0 and a.numel() > 0:
+            # the nine halving steps in one launch (ops/csrc/smallk.hip) instead of ten tiny kernels each
+            mid = ops.minmax_bisect(a.float(), b.float(), c, threshold, 0.0, 5.0, 0.01)
+            hi_f = lo_f
         while abs(hi_f - lo_f) > 0.01:  # fixed trip count: the interval halves every time
             mid = (low + high) / 2
             loss = (a - 2 * mid * b + mid * mid * c).clamp_min(0).max().sqrt()

@@ -215,6 +215,11 @@ def smallk_max(device) -> int:
     return int(_h().SMALLK_MAX)
 
 
+def minmax_bisect(a, b, c, thr, lo, hi, tol):
+    """The min-max attack's bisection in one launch (GPU): 0-d tensor gamma."""
+    return _h().minmax_bisect(a, b, c, thr, lo, hi, tol)
+
+
 def cclip(G, p, mm, n_iter, tau):
     """Centred-clipping coefficients (c0, c) from the Gram matrix in one launch (K <= smallk_max)."""
     return _h().cclip(G, p, mm, n_iter, tau)

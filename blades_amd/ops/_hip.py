@@ -333,7 +333,22 @@ _smallk_max = _opt_sig("blades_smallk_max", [], c_int)
 _power_top = _opt_sig("blades_power_top", [_P, c_int, c_int, _P, _P], c_int)
 _weiszfeld = _opt_sig("blades_weiszfeld", [_P, _P, c_int, c_int, ctypes.c_double, ctypes.c_double, _P, _P, _P], c_int)
 _cclip = _opt_sig("blades_cclip", [_P, _P, _P, c_int, c_int, ctypes.c_double, _P, _P], c_int)
+_minmax_bisect = _opt_sig("blades_minmax_bisect", [_P, _P, c_int, _P, _P, c_float, c_float, c_float, _P, _P], c_int)
 SMALLK_MAX = int(_smallk_max()) if _smallk_max is not None else 0
+
+
+def minmax_bisect(a, b, c, thr, lo: float, hi: float, tol: float):
+    """Bisection of the min-max attack in one launch: the last midpoint gamma tried in [lo, hi] (halving until the
+    interval is <= tol) under ``sqrt(max_i max(a_i - 2 gamma b_i + gamma^2 c, 0)) < thr``.  0-d fp32 tensor."""
+    n = int(a.numel())
+    a = _vec(a, n, a.device, name="a")
+    b = _vec(b, n, a.device, name="b")
+    c = c.reshape(1).to(device=a.device, dtype=torch.float32)
+    thr = thr.reshape(1).to(device=a.device, dtype=torch.float32)
+    out = _empty(1, device=a.device)
+    if _minmax_bisect(_ptr(a), _ptr(b), n, _ptr(c), _ptr(thr), float(lo), float(hi), float(tol), _ptr(out), _stream()) != 0:
+        raise ValueError("minmax_bisect: rejected")
+    return out.reshape(())
 
 
 def cclip(G, p, mm, n_iter: int, tau: float):

@@ -108,6 +108,38 @@ __global__ __launch_bounds__(TPB) void weiszfeld_kernel(const float* __restrict_
   if (t == 0) *iters_out = it;
 }
 
+// Bisection of the min-max attack (adversaries/optimized.py::MinMaxAdversary; reference
+// blades/adversaries/minmax_adversary.py:37-63): the largest gamma in [lo, hi] (halving until the interval is <= tol)
+// with sqrt(max_i max(a_i - 2 gamma b_i + gamma^2 c, 0)) < threshold.  Same fp32 operations, in the same order, as
+// the tensor form it replaces (ten tiny launches per halving step).  Any n; one workgroup.
+__global__ __launch_bounds__(TPB) void minmax_bisect_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                            const float* __restrict__ c_ptr,
+                                                            const float* __restrict__ thr_ptr, float lo, float hi,
+                                                            float tol, float* __restrict__ out) {
+  __shared__ float red[TPB];
+  const int t = threadIdx.x;
+  const float c = *c_ptr, thr = *thr_ptr;
+  float low = lo, high = hi, mid = __fmul_rn(__fadd_rn(low, high), 0.5f);
+  float lo_f = lo, hi_f = hi;
+  while (fabsf(hi_f - lo_f) > tol) {
+    mid = __fmul_rn(__fadd_rn(low, high), 0.5f);
+    const float two_mid = __fmul_rn(2.f, mid), mid2c = __fmul_rn(__fmul_rn(mid, mid), c);
+    float m = 0.f;  // = clamp_min(., 0) of the maximum
+    for (int i = t; i < n; i += TPB) m = fmaxf(m, __fadd_rn(__fadd_rn(a[i], -__fmul_rn(two_mid, b[i])), mid2c));
+    red[t] = m;
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+      if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+      __syncthreads();
+    }
+    const bool ok = sqrtf(red[0]) < thr;
+    __syncthreads();
+    if (ok) low = mid; else high = mid;
+    hi_f = lo_f + (hi_f - lo_f) * 0.5f;
+  }
+  if (t == 0) *out = mid;
+}
+
 // out[0] = c0, out[1 + j] = c_j (fp64)
 __global__ __launch_bounds__(TPB) void cclip_kernel(const float* __restrict__ G, const float* __restrict__ pvec,
                                                     const float* __restrict__ mm_ptr, int K, int n_iter, double tau,
@@ -161,6 +193,14 @@ BLADES_API int blades_cclip(const float* G, const float* p, const float* mm, int
     attr = true;
   }
   hipLaunchKernelGGL(cclip_kernel, dim3(1), dim3(TPB), lds, st, G, p, mm, K, n_iter, tau, out);
+  return 0;
+}
+
+// a, b: [n] fp32; c, thr: one fp32 each (device); out: one fp32 (the last midpoint tried, as the tensor loop returns it)
+BLADES_API int blades_minmax_bisect(const float* a, const float* b, int n, const float* c, const float* thr, float lo,
+                                    float hi, float tol, float* out, hipStream_t st) {
+  if (n < 1 || !(hi > lo) || !(tol > 0.f) || (hi - lo) / tol > 1e9f) return 1;
+  hipLaunchKernelGGL(minmax_bisect_kernel, dim3(1), dim3(TPB), 0, st, a, b, n, c, thr, lo, hi, tol, out);
   return 0;
 }
 
