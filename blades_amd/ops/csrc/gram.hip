@@ -262,10 +262,145 @@ __global__ __launch_bounds__(256, 2) void gram_planes_kernel(const float* __rest
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        // (in a diagonal tile (r, c) and (c, r) are sums in different plane order: the upper one serves both)
         const int row = ti * B + wr * 64 + a * 16 + kg * 4 + q;
         const int col = tj * B + wc * 64 + b * 16 + li;
+        if (row > col) continue;
         slab[(long)row * Kp + col] = acc[a][b][q];
+        if (ti == tj && row != col) slab[(long)col * Kp + row] = acc[a][b][q];
       }
+}
+
+// ---- K <= 128: the whole Gram matrix is one tile (round 3) ---------------------------------------------------------
+// With a single 128-row tile the planes kernel stages the same rows twice (A and B images of a diagonal tile) and
+// computes all 64 fragments although 36 are distinct; at K <= 64 the fp32-MFMA tile kernel runs at 1/16 of the bf16
+// rate.  Here one image [3 planes][16 NF rows][32 k] serves both operands and the NF (NF + 1) / 2 fragments of the
+// upper triangle are dealt over the four waves (NF = 8: wave w takes row band w and row band 7 - w, 9 fragments each,
+// the band's a-fragments read once; NF = 4: fragment w + 4 s of the row-major upper triangle).  The mirror image is
+// written by the same wave from the same registers, so G stays bitwise symmetric, and every entry is still produced
+// by the one instruction sequence (identical rows cancel exactly, see above).
+template <int NF>
+__global__ __launch_bounds__(256, 2) void gram_small_kernel(const float* __restrict__ U, long ld, int K, long Dl,
+                                                            long cols_per_split, int nsplit, float* __restrict__ slabs) {
+  constexpr int B = 16 * NF, PLANE = B * 64, SLOTS = (NF * (NF + 1) / 2 + 3) / 4;
+  __shared__ __attribute__((aligned(16))) unsigned char As[3 * PLANE];
+  const int split = blockIdx.x;
+  if (split >= nsplit) return;
+  const long c_begin = (long)split * cols_per_split;
+  long c_end = c_begin + cols_per_split;
+  if (c_end > Dl) c_end = Dl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  const bool al = (ld & 3) == 0;
+  auto swz = [](int row) { return (row & 4) << 3; };
+
+  // fragment (fi, fj) of slot s; fi < 0: none
+  int fi[SLOTS], fj[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    if constexpr (NF == 8) {
+      const int n1 = 8 - wave;
+      fi[s] = s < n1 ? wave : 7 - wave;
+      fj[s] = s < n1 ? wave + s : 7 - wave + (s - n1);
+    } else {
+      int idx = wave + 4 * s, r = 0;
+      if (idx >= NF * (NF + 1) / 2) { fi[s] = -1; fj[s] = 0; continue; }
+      while (idx >= NF - r) { idx -= NF - r; ++r; }
+      fi[s] = r; fj[s] = r + idx;
+    }
+  }
+  f32x4 acc[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int LOADS = B * (BK / 4) / 256;
+  f32x4 ra[LOADS];
+  auto fetch = [&](long c0) {
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int f = q * 256 + tid;
+      const int row = f >> 3, k4 = (f & 7) * 4;
+      const long col = c0 + k4;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f};
+      if (row < K) {
+        if (col + 4 <= c_end && al) va = *reinterpret_cast<const f32x4*>(U + (long)row * ld + col);
+        else
+          for (int j = 0; j < 4; ++j)
+            if (col + j < c_end) va[j] = U[(long)row * ld + col + j];
+      }
+      ra[q] = va;
+    }
+  };
+  auto frag = [&](int f, bf16x8 (&out)[3]) {
+    const int row = f * 16 + li;
+    const unsigned char* src = As + row * 64 + ((kg * 16) ^ swz(row));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q] = *reinterpret_cast<const bf16x8*>(src + q * PLANE);
+  };
+  auto six = [](f32x4 c, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    // small terms first; (a plane, b plane) — the order of gram_planes_kernel
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+    return c;
+  };
+  if (c_begin < c_end) fetch(c_begin);
+  for (long c0 = c_begin; c0 < c_end; c0 += BK) {
+    __syncthreads();  // previous step's fragment reads done
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) {
+      const int f = q * 256 + tid;
+      const int row = f >> 3, k4 = (f & 7) * 4;
+      unsigned char* dst = As + row * 64 + (((k4 >> 3) * 16) ^ swz(row)) + ((k4 >> 2) & 1) * 8;
+      f32x4 r = ra[q];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const bf16x4 b = __builtin_convertvector(r, bf16x4);
+        *reinterpret_cast<u32x2*>(dst + p * PLANE) = __builtin_bit_cast(u32x2, b);
+        if (p < 2) r -= __builtin_convertvector(b, f32x4);
+      }
+    }
+    __syncthreads();
+    if (c0 + BK < c_end) fetch(c0 + BK);
+    if constexpr (NF == 8) {
+      bf16x8 a1[3], a2[3];
+      frag(wave, a1);
+      frag(7 - wave, a2);
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        bf16x8 bfr[3];
+        frag(fj[s], bfr);
+        if (s < 8 - wave) acc[s] = six(acc[s], a1, bfr);
+        else acc[s] = six(acc[s], a2, bfr);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        if (fi[s] < 0) continue;
+        bf16x8 afr[3], bfr[3];
+        frag(fi[s], afr);
+        frag(fj[s], bfr);
+        acc[s] = six(acc[s], afr, bfr);
+      }
+    }
+  }
+  // C/D map of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+  float* slab = slabs + (long)split * B * B;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    if (fi[s] < 0) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // (a diagonal fragment holds (r, c) and (c, r) as sums in different plane order: keep the upper one)
+      const int row = fi[s] * 16 + kg * 4 + q, col = fj[s] * 16 + li;
+      if (row > col) continue;
+      slab[(long)row * B + col] = acc[s][q];
+      if (row != col) slab[(long)col * B + row] = acc[s][q];
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nsplit, int Kp, int K,
@@ -279,6 +414,38 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   float acc = 0.f;
   for (int s = 0; s < nsplit; ++s) acc += slabs[(long)s * Kp * Kp + (long)si * Kp + sj];
   out[idx] = acc;
+}
+
+// Many splits, few entries (K <= 128 has up to 1024 slabs for 16 K entries, 32 splits and more take this kernel): a thread per entry walks 1024 strided
+// loads on 14 workgroups — 0.25 ms of latency, more than the product itself.  Here a workgroup takes 32 entries x 8
+// split lanes (lane l adds slabs l, l + 8, ... in order), and the lanes are combined in lane order: still one fixed
+// summation order.
+__global__ __launch_bounds__(256) void gram_reduce_lanes_kernel(const float* __restrict__ slabs, int nsplit, int Kp, int K,
+                                                                int B, float* __restrict__ out) {
+  __shared__ float part[8][33];
+  const int e = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const long idx = (long)blockIdx.x * 32 + e;
+  float acc = 0.f;
+  if (idx < (long)K * K) {
+    int i = (int)(idx / K), j = (int)(idx % K);
+    if (i / B > j / B) { const int t = i; i = j; j = t; }  // only tiles with tile_row <= tile_col were computed
+    const float* src = slabs + (long)i * Kp + j;
+    const long stride = (long)Kp * Kp;
+    int s = l;
+    for (; s + 24 < nsplit; s += 32) {
+      const float a = src[s * stride], b = src[(s + 8) * stride], c = src[(s + 16) * stride], d = src[(s + 24) * stride];
+      acc += a; acc += b; acc += c; acc += d;
+    }
+    for (; s < nsplit; s += 8) acc += src[s * stride];
+  }
+  part[l][e] = acc;
+  __syncthreads();
+  if (l == 0 && idx < (long)K * K) {
+    float t = part[0][e];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += part[q][e];
+    out[idx] = t;
+  }
 }
 
 }  // namespace
@@ -310,12 +477,23 @@ BLADES_API void blades_gram(const float* U, long ld, int K, long Dl, float* slab
   const int grid = (pairs * nsplit + 7) / 8 * 8;
   static const bool no_xcd = [] { const char* e = getenv("BLADES_GRAM_XCD"); return e && atoi(e) == 0; }();
   if (no_xcd) nsplit = -nsplit;
-  if (B == 64)
+  static const bool no_small = [] { const char* e = getenv("BLADES_GRAM_SMALL"); return e && atoi(e) == 0; }();
+  if (nt == 1 && !f32_only && !no_small) {
+    // (one launch item per column split: no XCD sharing to arrange)
+    const int n1 = nsplit < 0 ? -nsplit : nsplit;
+    if (B == 64)
+      hipLaunchKernelGGL((gram_small_kernel<4>), dim3(n1), dim3(256), 0, st, U, ld, K, Dl, cps, n1, slabs);
+    else
+      hipLaunchKernelGGL((gram_small_kernel<8>), dim3(n1), dim3(256), 0, st, U, ld, K, Dl, cps, n1, slabs);
+  } else if (B == 64)
     hipLaunchKernelGGL((gram_tile_kernel<64>), dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
   else if (f32_only)
     hipLaunchKernelGGL((gram_tile_kernel<128>), dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
   else
     hipLaunchKernelGGL(gram_planes_kernel, dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)K * K, 256)), dim3(256), 0, st, slabs,
-                     nsplit < 0 ? -nsplit : nsplit, Kp, K, B, out);
+  const int ns = nsplit < 0 ? -nsplit : nsplit;
+  if (ns >= 32)
+    hipLaunchKernelGGL(gram_reduce_lanes_kernel, dim3(cdiv((long)K * K, 32)), dim3(256), 0, st, slabs, ns, Kp, K, B, out);
+  else
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)K * K, 256)), dim3(256), 0, st, slabs, ns, Kp, K, B, out);
 }

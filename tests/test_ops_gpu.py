@@ -102,15 +102,15 @@ def test_row_reductions(dev, K, D):
     torch.testing.assert_close(ops.row_sqnorm(U), rsq, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("K,D", SHAPES + [(130, 5000), (257, 300)])
+@pytest.mark.parametrize("K,D", SHAPES + [(130, 5000), (257, 300), (1, 50), (16, 100), (64, 3000), (65, 3001), (100, 50001),
+                                         (128, 4096)])
 def test_gram(dev, K, D):
     U = make(K, D, dev)
     G = ops.gram(U)
     R = (U.double() @ U.double().t()).float()
     torch.testing.assert_close(G, R, rtol=1e-4, atol=1e-3 * max(1.0, D ** 0.5 / 10))
-    # asymmetric check: G must equal its transpose exactly where mirrored, and the
-    # diagonal must match row norms
-    assert torch.equal(G, G.t()) or torch.allclose(G, G.t(), rtol=0, atol=1e-4)
+    # bitwise symmetric: the lower triangle is a copy of the upper one
+    assert torch.equal(G, G.t())
 
 
 def test_gram_identical_rows_cancel_exactly(dev):
@@ -121,6 +121,13 @@ def test_gram_identical_rows_cancel_exactly(dev):
     d = G[5, 5] + G[200, 200] - 2 * G[5, 200]
     assert float(d) == 0.0
     assert float(G[17, 17] + G[5, 5] - 2 * G[17, 5]) == 0.0
+    # one-tile kernel (K <= 128): fragments of different waves
+    for K in (60, 128):
+        U = make(K, 70001, dev)
+        U[K - 1] = U[3]
+        G = ops.gram(U)
+        assert float(G[3, 3] + G[K - 1, K - 1] - 2 * G[3, K - 1]) == 0.0
+        assert torch.equal(G, G.t())
 
 
 def test_row_scale_set_rows_forge(dev):

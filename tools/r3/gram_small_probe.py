@@ -9,7 +9,7 @@ def timeit(fn, n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-for K, D in ((60, 4_903_242), (60, 1_475_146), (100, 4_903_242), (128, 4_903_242)):
+for K, D in ((60, 4_903_242), (60, 1_475_146), (100, 4_903_242), (128, 4_903_242), (200, 4_903_242), (300, 1_475_146)):
     U = torch.randn(K, (D + 255) // 256 * 256, device=dev)[:, :D]
     w = torch.rand(K, device=dev)
     m = torch.randn(D, device=dev)
