@@ -203,8 +203,10 @@ def power_iteration_top(G, iters=8):
     Small client counts (K <= 128, the reference's 60-client experiments): one launch of ops/csrc/smallk.hip with G in
     LDS — the ~30 library calls of the reference form cost 0.7 ms of launch overhead per call at that size.  Larger K:
     six squarings + ``iters`` matrix-vector products on library GEMMs (K = 1000: 6 GEMMs of 1000^3), no host sync."""
-    if G.is_cuda and not _FORCE_REFERENCE and G.dtype == torch.float32 and 1 <= G.shape[0] <= _h().SMALLK_MAX:
-        return _h().power_top(G, 64 + int(iters))
+    if G.is_cuda and not _FORCE_REFERENCE and G.dtype == torch.float32 and 1 <= G.shape[-1] <= _h().SMALLK_MAX:
+        return _h().power_top(G, 64 + int(iters))  # (a [B, K, K] stack: one workgroup per matrix)
+    if G.dim() == 3:
+        return torch.stack([ref.power_iteration_top(g, iters) for g in G])
     return ref.power_iteration_top(G, iters)
 
 

@@ -330,7 +330,7 @@ def gram(U):
 
 
 _smallk_max = _opt_sig("blades_smallk_max", [], c_int)
-_power_top = _opt_sig("blades_power_top", [_P, c_int, c_int, _P, _P], c_int)
+_power_top = _opt_sig("blades_power_top", [_P, c_int, c_int, c_int, _P, _P], c_int)
 _weiszfeld = _opt_sig("blades_weiszfeld", [_P, _P, c_int, c_int, ctypes.c_double, ctypes.c_double, _P, _P, _P], c_int)
 _cclip = _opt_sig("blades_cclip", [_P, _P, _P, c_int, c_int, ctypes.c_double, _P, _P], c_int)
 _minmax_bisect = _opt_sig("blades_minmax_bisect", [_P, _P, c_int, _P, _P, c_float, c_float, c_float, _P, _P], c_int)
@@ -367,14 +367,16 @@ def cclip(G, p, mm, n_iter: int, tau: float):
 
 
 def power_top(G, steps: int):
-    """Top eigenvector of a symmetric PSD fp32 ``[K, K]`` matrix, K <= SMALLK_MAX, by ``steps`` normalised power steps
-    in one launch (ops/csrc/smallk.hip)."""
-    K = int(G.shape[0])
-    if not (G.is_cuda and G.dtype == torch.float32 and G.dim() == 2 and G.shape[1] == K and 1 <= K <= SMALLK_MAX):
-        raise ValueError(f"power_top: expected a CUDA fp32 [K, K] matrix with K <= {SMALLK_MAX}")
+    """Top eigenvector of a symmetric PSD fp32 ``[K, K]`` matrix (or of each matrix of a ``[B, K, K]`` stack),
+    K <= SMALLK_MAX, by ``steps`` normalised power steps in one launch (ops/csrc/smallk.hip)."""
+    K = int(G.shape[-1])
+    if not (G.is_cuda and G.dtype == torch.float32 and G.dim() in (2, 3) and G.shape[-2] == K and 1 <= K <= SMALLK_MAX
+            and G.shape[0] >= 1):
+        raise ValueError(f"power_top: expected a CUDA fp32 [K, K] or [B, K, K] matrix with K <= {SMALLK_MAX}")
     G = G.contiguous()
-    out = _empty(K, device=G.device)
-    if _power_top(_ptr(G), K, int(steps), _ptr(out), _stream()) != 0:
+    nb = 1 if G.dim() == 2 else int(G.shape[0])
+    out = _empty(K, device=G.device) if G.dim() == 2 else _empty(nb, K, device=G.device)
+    if _power_top(_ptr(G), K, nb, int(steps), _ptr(out), _stream()) != 0:
         raise ValueError("power_top: rejected")
     return out
 

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(TPB) void power_top_kernel(const float* __restrict_
   float* v = g + K * (K + 1);        // [K]
   float* red = v + KMAX;             // [TPB]
   const int t = threadIdx.x;
+  G += (size_t)blockIdx.x * K * K;  // one matrix per workgroup
+  out += (size_t)blockIdx.x * K;
   for (int i = t; i < K * K; i += TPB) g[(i / K) * (K + 1) + (i % K)] = G[i];
   if (t < K) v[t] = 1.0f / sqrtf((float)K) + (float)t * (1e-3f / (float)K);
   __syncthreads();
@@ -206,9 +208,9 @@ BLADES_API int blades_minmax_bisect(const float* a, const float* b, int n, const
 
 BLADES_API int blades_smallk_max() { return KMAX; }
 
-// G: [K, K] fp32 contiguous, symmetric.  out: [K].  returns 0 ok.
-BLADES_API int blades_power_top(const float* G, int K, int steps, float* out, hipStream_t st) {
-  if (K < 1 || K > KMAX || steps < 1 || steps > 100000) return 1;
+// G: nb matrices [K, K] fp32 contiguous, symmetric.  out: [nb, K].  returns 0 ok.
+BLADES_API int blades_power_top(const float* G, int K, int nb, int steps, float* out, hipStream_t st) {
+  if (K < 1 || K > KMAX || steps < 1 || steps > 100000 || nb < 1 || nb > 65535) return 1;
   const size_t lds = ((size_t)K * (K + 1) + KMAX + TPB) * sizeof(float);
   static bool attr = false;
   if (!attr) {
@@ -216,7 +218,7 @@ BLADES_API int blades_power_top(const float* G, int K, int steps, float* out, hi
                               (KMAX * (KMAX + 1) + KMAX + TPB) * (int)sizeof(float));
     attr = true;
   }
-  hipLaunchKernelGGL(power_top_kernel, dim3(1), dim3(TPB), lds, st, G, K, steps, out);
+  hipLaunchKernelGGL(power_top_kernel, dim3(nb), dim3(TPB), lds, st, G, K, steps, out);
   return 0;
 }
 

@@ -893,6 +893,56 @@ def test_aggregators_gpu_match_cpu(dev, name, kw):
         torch.testing.assert_close(out_g.cpu(), out_c, rtol=2e-3, atol=2e-4)
 
 
+def test_dnc_device_sampler_and_batched_iterations(dev):
+    """DnC on GPU tensors (aggregators/simple.py): index sets drawn on the device (distinct, in range, a function of
+    (seed, call counter) only) and, for K <= 128 on one GPU, all iterations in one batch — same kept set as the
+    per-iteration loop on the same index sets."""
+    from blades_amd import aggregators as A
+    from blades_amd.parallel.context import local_context
+
+    K, D, f = 30, 60011, 6
+    g = torch.Generator().manual_seed(3)
+    U = (torch.randn(K, D, generator=g) * 0.1)
+    U[:f] += 0.4
+    U = U.to(dev)
+    ctx = local_context(D)
+    a = A.DnC(num_byzantine=f, sub_dim=2000, num_iters=5, seed=11)
+    idx = a._sample_columns_device(D, U.device, 5)
+    assert idx.shape == (5, 2000) and idx.dtype == torch.int64
+    assert int(idx.min()) >= 0 and int(idx.max()) < D
+    for row in idx.cpu():
+        assert row.unique().numel() == 2000
+    assert not torch.equal(idx[0], idx[1])
+    b = A.DnC(num_byzantine=f, sub_dim=2000, num_iters=5, seed=11)
+    assert torch.equal(idx, b._sample_columns_device(D, U.device, 5))       # same (seed, calls): same draw
+    assert not torch.equal(idx, b._sample_columns_device(D, U.device, 5))   # the call counter moved on
+    assert a.state_dict() == {"calls": 5}
+    # uniformity, roughly: mean of the drawn ids is D / 2 within 5 standard errors
+    se = D / (12 ** 0.5) / (5 * 2000) ** 0.5
+    assert abs(float(idx.double().mean()) - (D - 1) / 2) < 5 * se
+    # small or dense draws and sampler="numpy" stay on the host sampler
+    assert A.DnC(num_byzantine=f, sub_dim=500)._sample_columns_device(D, U.device, 5) is None
+    assert A.DnC(num_byzantine=f, sub_dim=20000)._sample_columns_device(D, U.device, 5) is None
+    assert A.DnC(num_byzantine=f, sub_dim=2000, sampler="numpy")._sample_columns_device(D, U.device, 5) is None
+
+    # batched path vs the loop on the same indices (a distributed-looking context takes the loop)
+    a1 = A.DnC(num_byzantine=f, sub_dim=2000, num_iters=5, seed=5)
+    a2 = A.DnC(num_byzantine=f, sub_dim=2000, num_iters=5, seed=5)
+    out1 = a1.aggregate(U, ctx)
+
+    class _Loop:
+        distributed = True
+        d_total, d_valid, col_offset = D, D, 0
+
+        def all_reduce(self, t):
+            return t
+
+    out2 = a2.aggregate(U, _Loop())
+    assert int(a1.last_info["num_selected"]) == int(a2.last_info["num_selected"]) == K - f
+    torch.testing.assert_close(out1, out2, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(out1, U[f:].mean(0), rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("K", [5, 60, 128])
 def test_small_client_count_gram_solvers(dev, K):
     """ops/csrc/smallk.hip: the single-launch power iteration (DnC) and Weiszfeld loop (GeoMed) on a K x K Gram matrix
