@@ -229,12 +229,9 @@ class DnC(Aggregator):
         idx_all = self._sample_columns_device(ctx.d_total, U.device, self.num_iters) if self.num_iters > 0 else None
         if idx_all is not None and not ctx.distributed and K <= ops.smallk_max(U.device):
             # small client counts on one GPU: all iterations at once (one gather, one batched Gram product, one
-            # launch for the power iterations) — ~15 launches instead of ~60
-            iters, n = idx_all.shape
-            S = U.index_select(1, idx_all.reshape(-1)).view(K, iters, n)
-            S = S - S.mean(dim=0, keepdim=True)
-            Sb = S.permute(1, 0, 2)
-            G = torch.bmm(Sb, Sb.transpose(1, 2))
+            # launch for the power iterations) — ~12 launches instead of ~60
+            # (colgather.hip: gather + centre; gram.hip: one-tile kernel, a grid row per iteration; smallk.hip)
+            G = ops.gram_batched(ops.gather_center_cols(U, idx_all))
             u = ops.power_iteration_top(G, self.power_iters)  # [iters, K]
             good = torch.topk(u * u, n_keep, dim=1, largest=False).indices
             keep_mask[good.reshape(-1)] = True
@@ -247,9 +244,7 @@ class DnC(Aggregator):
                 sel = idx[(idx >= lo) & (idx < lo + ctx.d_valid)] - lo
             else:
                 sel = idx
-            S = U.index_select(1, sel)
-            S = S - S.mean(dim=0, keepdim=True)
-            G = global_gram(S.contiguous(), ctx) if S.shape[1] > 0 else ctx.all_reduce(
+            G = global_gram(ops.gather_center_cols(U, sel.unsqueeze(0))[0], ctx) if sel.numel() > 0 else ctx.all_reduce(
                 torch.zeros(K, K, device=U.device))
             u = ops.power_iteration_top(G, self.power_iters)
             score = u * u  # proportional to ((S_i - mu) . v)^2

@@ -125,6 +125,22 @@ def gram(U):
     return ref.gram(U)
 
 
+def gram_batched(S):
+    """Gram matrices of a stack ``[B, K, n]`` (DnC's iterations): one launch for K <= 128 on the GPU."""
+    if S.is_cuda and not _FORCE_REFERENCE and S.dtype == torch.float32 and S.dim() == 3 and 1 <= S.shape[1] <= 128:
+        return _h().gram_batched(S.contiguous())
+    if S.is_cuda and not _FORCE_REFERENCE and S.dtype == torch.float32:
+        return torch.stack([gram(s) for s in S])
+    return ref.gram_batched(S)
+
+
+def gather_center_cols(U, idx):
+    """Centred column sub-samples ``[iters, K, n]`` of ``U`` at the column ids ``idx[iters, n]``."""
+    if _use_hip(_f32c(U)):
+        return _h().gather_center_cols(U, idx.to(U.device))
+    return ref.gather_center_cols(U, idx)
+
+
 def row_scale_(U, s):
     if _use_hip(_f32c(U)):
         return _h().row_scale_(U, s)

@@ -329,6 +329,41 @@ def gram(U):
     return out
 
 
+_gram_batched = _opt_sig("blades_gram_batched", [_P, c_long, c_long, c_int, c_int, c_long, _P, _P, _P], c_int)
+_gather_center = _opt_sig("blades_gather_center", [_P, c_long, c_int, c_long, _P, c_long, c_long, _P, _P], c_int)
+
+
+def gram_batched(S):
+    """``S[b] S[b]^T`` for a contiguous fp32 stack ``[B, K, n]`` with K <= 128 (one-tile kernel of gram.hip, a grid row
+    per matrix): ``[B, K, K]``."""
+    if not (S.is_cuda and S.dtype == torch.float32 and S.dim() == 3 and S.is_contiguous() and 1 <= S.shape[1] <= 128
+            and S.shape[0] >= 1):
+        raise ValueError("gram_batched: expected a contiguous CUDA fp32 [B, K <= 128, n] stack")
+    nb, K, n = (int(v) for v in S.shape)
+    tile, ntile, nsplit, cps = c_int(), c_int(), c_int(), c_long()
+    _gram_plan(K, n, ctypes.byref(tile), ctypes.byref(ntile), ctypes.byref(nsplit), ctypes.byref(cps))
+    Kp = tile.value * ntile.value
+    slabs = _empty(nb * max(nsplit.value, 1) * Kp * Kp, device=S.device)
+    out = _empty(nb, K, K, device=S.device)
+    if _gram_batched(_ptr(S), n, K * n, nb, K, n, _ptr(slabs), _ptr(out), _stream()) != 0:
+        raise ValueError("gram_batched: rejected")
+    return out
+
+
+def gather_center_cols(U, idx):
+    """``out[i, k, j] = U[k, idx[i, j]] - mean_k U[k, idx[i, j]]`` (colgather.hip): the centred column sub-samples of
+    DnC, ``[iters, K, n]`` fp32 contiguous.  ``idx``: int64 ``[iters, n]`` on the device."""
+    K, Dl, ld = _chk_matrix(U)
+    if not (idx.is_cuda and idx.dtype == torch.int64 and idx.dim() == 2 and idx.numel() > 0):
+        raise ValueError("gather_center_cols: idx must be a non-empty CUDA int64 [iters, n] tensor")
+    idx = idx.contiguous()
+    iters, n = int(idx.shape[0]), int(idx.shape[1])
+    out = _empty(iters, K, n, device=U.device)
+    if _gather_center(_ptr(U), ld, K, Dl, _ptr(idx), iters, n, _ptr(out), _stream()) != 0:
+        raise ValueError("gather_center_cols: rejected")
+    return out
+
+
 _smallk_max = _opt_sig("blades_smallk_max", [], c_int)
 _power_top = _opt_sig("blades_power_top", [_P, c_int, c_int, c_int, _P, _P], c_int)
 _weiszfeld = _opt_sig("blades_weiszfeld", [_P, _P, c_int, c_int, ctypes.c_double, ctypes.c_double, _P, _P, _P], c_int)

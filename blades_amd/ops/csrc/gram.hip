@@ -281,11 +281,14 @@ __global__ __launch_bounds__(256, 2) void gram_planes_kernel(const float* __rest
 // by the one instruction sequence (identical rows cancel exactly, see above).
 template <int NF>
 __global__ __launch_bounds__(256, 2) void gram_small_kernel(const float* __restrict__ U, long ld, int K, long Dl,
-                                                            long cols_per_split, int nsplit, float* __restrict__ slabs) {
+                                                            long cols_per_split, int nsplit, float* __restrict__ slabs,
+                                                            long u_bs) {
   constexpr int B = 16 * NF, PLANE = B * 64, SLOTS = (NF * (NF + 1) / 2 + 3) / 4;
   __shared__ __attribute__((aligned(16))) unsigned char As[3 * PLANE];
   const int split = blockIdx.x;
   if (split >= nsplit) return;
+  U += (size_t)blockIdx.y * u_bs;  // a stack of matrices: one grid row each
+  slabs += (size_t)blockIdx.y * nsplit * B * B;
   const long c_begin = (long)split * cols_per_split;
   long c_end = c_begin + cols_per_split;
   if (c_end > Dl) c_end = Dl;
@@ -407,6 +410,8 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
                                                           int B, float* __restrict__ out) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)K * K) return;
+  slabs += (size_t)blockIdx.y * nsplit * Kp * Kp;
+  out += (size_t)blockIdx.y * K * K;
   const int i = (int)(idx / K), j = (int)(idx % K);
   // only tiles with tile_row <= tile_col were computed
   int si = i, sj = j;
@@ -425,6 +430,8 @@ __global__ __launch_bounds__(256) void gram_reduce_lanes_kernel(const float* __r
   __shared__ float part[8][33];
   const int e = threadIdx.x & 31, l = threadIdx.x >> 5;
   const long idx = (long)blockIdx.x * 32 + e;
+  slabs += (size_t)blockIdx.y * nsplit * Kp * Kp;
+  out += (size_t)blockIdx.y * K * K;
   float acc = 0.f;
   if (idx < (long)K * K) {
     int i = (int)(idx / K), j = (int)(idx % K);
@@ -465,35 +472,53 @@ BLADES_API void blades_gram_plan(int K, long Dl, int* tile, int* ntile, int* nsp
   *tile = B; *ntile = nt; *cols_per_split = sps * BK; *nsplit = cdiv(Dl, sps * BK);
 }
 
-// slabs: workspace of nsplit * Kp * Kp floats, Kp = ntile * tile
-BLADES_API void blades_gram(const float* U, long ld, int K, long Dl, float* slabs, float* out, hipStream_t st) {
-  if (K <= 0) return;
+namespace {
+
+void gram_launch(const float* U, long ld, long u_bs, int nb, int K, long Dl, float* slabs, float* out, hipStream_t st) {
   int B, nt, nsplit; long cps;
   blades_gram_plan(K, Dl, &B, &nt, &nsplit, &cps);
   const int Kp = nt * B, pairs = nt * (nt + 1) / 2;
-  if (Dl <= 0) { hipMemsetAsync(out, 0, sizeof(float) * K * K, st); return; }
-  // BLADES_GRAM_IMPL=f32: the exact-fp32 MFMA kernel for every size (A/B runs); default: bf16 planes for 128-row tiles
+  if (Dl <= 0) { (void)hipMemsetAsync(out, 0, sizeof(float) * nb * K * K, st); return; }
+  // BLADES_GRAM_IMPL=f32: the exact-fp32 MFMA kernel for every size (A/B runs); default: bf16 planes
   static const bool f32_only = [] { const char* e = getenv("BLADES_GRAM_IMPL"); return e && e[0] == 'f'; }();
   const int grid = (pairs * nsplit + 7) / 8 * 8;
   static const bool no_xcd = [] { const char* e = getenv("BLADES_GRAM_XCD"); return e && atoi(e) == 0; }();
-  if (no_xcd) nsplit = -nsplit;
   static const bool no_small = [] { const char* e = getenv("BLADES_GRAM_SMALL"); return e && atoi(e) == 0; }();
-  if (nt == 1 && !f32_only && !no_small) {
+  const int ns = nsplit;
+  if (nt == 1 && ((!f32_only && !no_small) || nb > 1)) {
     // (one launch item per column split: no XCD sharing to arrange)
-    const int n1 = nsplit < 0 ? -nsplit : nsplit;
     if (B == 64)
-      hipLaunchKernelGGL((gram_small_kernel<4>), dim3(n1), dim3(256), 0, st, U, ld, K, Dl, cps, n1, slabs);
+      hipLaunchKernelGGL((gram_small_kernel<4>), dim3(ns, nb), dim3(256), 0, st, U, ld, K, Dl, cps, ns, slabs, u_bs);
     else
-      hipLaunchKernelGGL((gram_small_kernel<8>), dim3(n1), dim3(256), 0, st, U, ld, K, Dl, cps, n1, slabs);
-  } else if (B == 64)
-    hipLaunchKernelGGL((gram_tile_kernel<64>), dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
-  else if (f32_only)
-    hipLaunchKernelGGL((gram_tile_kernel<128>), dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
-  else
-    hipLaunchKernelGGL(gram_planes_kernel, dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
-  const int ns = nsplit < 0 ? -nsplit : nsplit;
+      hipLaunchKernelGGL((gram_small_kernel<8>), dim3(ns, nb), dim3(256), 0, st, U, ld, K, Dl, cps, ns, slabs, u_bs);
+  } else {
+    if (no_xcd) nsplit = -nsplit;
+    if (B == 64)
+      hipLaunchKernelGGL((gram_tile_kernel<64>), dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
+    else if (f32_only)
+      hipLaunchKernelGGL((gram_tile_kernel<128>), dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
+    else
+      hipLaunchKernelGGL(gram_planes_kernel, dim3(grid), dim3(256), 0, st, U, ld, K, Dl, cps, nt, Kp, nsplit, slabs);
+  }
   if (ns >= 32)
-    hipLaunchKernelGGL(gram_reduce_lanes_kernel, dim3(cdiv((long)K * K, 32)), dim3(256), 0, st, slabs, ns, Kp, K, B, out);
+    hipLaunchKernelGGL(gram_reduce_lanes_kernel, dim3(cdiv((long)K * K, 32), nb), dim3(256), 0, st, slabs, ns, Kp, K, B, out);
   else
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)K * K, 256)), dim3(256), 0, st, slabs, ns, Kp, K, B, out);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)K * K, 256), nb), dim3(256), 0, st, slabs, ns, Kp, K, B, out);
+}
+
+}  // namespace
+
+// slabs: workspace of nsplit * Kp * Kp floats, Kp = ntile * tile
+BLADES_API void blades_gram(const float* U, long ld, int K, long Dl, float* slabs, float* out, hipStream_t st) {
+  if (K <= 0) return;
+  gram_launch(U, ld, 0, 1, K, Dl, slabs, out, st);
+}
+
+// nb matrices of K <= 128 rows (one tile), matrix b at U + b * u_bs; slabs: nb * nsplit * Kp * Kp floats; out: [nb, K, K].
+// returns 0 ok.
+BLADES_API int blades_gram_batched(const float* U, long ld, long u_bs, int nb, int K, long Dl, float* slabs, float* out,
+                                   hipStream_t st) {
+  if (K < 1 || K > 128 || nb < 1 || nb > 65535) return 1;
+  gram_launch(U, ld, u_bs, nb, K, Dl, slabs, out, st);
+  return 0;
 }

@@ -101,6 +101,19 @@ def gram(U: torch.Tensor) -> torch.Tensor:
     return U @ U.t()
 
 
+def gram_batched(S: torch.Tensor) -> torch.Tensor:
+    """``S[b] @ S[b].T`` for a stack ``[B, K, n]``."""
+    return torch.bmm(S, S.transpose(1, 2))
+
+
+def gather_center_cols(U: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """``out[i, k, j] = U[k, idx[i, j]] - mean_k U[k, idx[i, j]]``: ``[iters, K, n]``."""
+    iters, n = idx.shape
+    S = U.index_select(1, idx.reshape(-1)).view(U.shape[0], iters, n)
+    S = S - S.mean(dim=0, keepdim=True)
+    return S.permute(1, 0, 2).contiguous()
+
+
 def row_scale_(U: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     """In-place ``U[i, :] *= s[i]``."""
     U.mul_(s.to(U.dtype).unsqueeze(1))

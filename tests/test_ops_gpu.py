@@ -925,6 +925,23 @@ def test_dnc_device_sampler_and_batched_iterations(dev):
     assert A.DnC(num_byzantine=f, sub_dim=20000)._sample_columns_device(D, U.device, 5) is None
     assert A.DnC(num_byzantine=f, sub_dim=2000, sampler="numpy")._sample_columns_device(D, U.device, 5) is None
 
+    # the two kernels of the batched path against their tensor forms
+    from blades_amd import ops
+    from blades_amd.ops import reference as ref
+    Uv = torch.randn(K, D + 5, device=dev)[:, 3:D + 3]  # odd row stride, unaligned start
+    S = ops.gather_center_cols(Uv, idx)
+    assert S.shape == (5, K, 2000) and S.is_contiguous()
+    torch.testing.assert_close(S, ref.gather_center_cols(Uv, idx), rtol=1e-6, atol=1e-6)
+    for shape in ((5, K, 2000), (3, 128, 1037), (1, 1, 40), (2, 64, 4096), (2, 65, 515)):
+        Sx = torch.randn(*shape, device=dev)
+        Gx = ops.gram_batched(Sx)
+        Rx = torch.bmm(Sx.double(), Sx.double().transpose(1, 2)).float()
+        torch.testing.assert_close(Gx, Rx, rtol=1e-4, atol=1e-3)
+        assert torch.equal(Gx, Gx.transpose(1, 2))
+        assert torch.equal(Gx[-1], ops.gram(Sx[-1]))  # the same kernel, the same split
+    vb = ops.power_iteration_top(ops.gram_batched(S), 8)
+    assert vb.shape == (5, K) and torch.equal(vb[2], ops.power_iteration_top(ops.gram(S[2]), 8))
+
     # batched path vs the loop on the same indices (a distributed-looking context takes the loop)
     a1 = A.DnC(num_byzantine=f, sub_dim=2000, num_iters=5, seed=5)
     a2 = A.DnC(num_byzantine=f, sub_dim=2000, num_iters=5, seed=5)
