@@ -39,6 +39,7 @@
 //     halo rows and all channel tiles of a pixel tile share the input through that XCD's L2).
 #include "common.h"
 #include <cstring>
+#include <algorithm>
 #include <cstdlib>
 
 #ifndef BLADES_AF_AHEAD
@@ -107,6 +108,8 @@ struct IgemmParams {
   const float* bstat_x;
   const unsigned char* bstat_mask;
   int stats_chunk0, stats_class, stats_classes;
+  int cr_taps;                // bf16 tensors (NPL = 1): > 0 = all weight tiles of a (segment, chunk) are resident in LDS
+                              // ([cr_taps][64 co][32 ci]) and the taps run without barriers (see the v1 kernel)
   int Hphys, Wphys, in_rm, in_cm;  // the input may be a strided view in[:, ::rm, ::cm] of a [Hphys][Wphys] image (a
                                    // strided 1x1 convolution only ever touches those pixels: it runs as a stride-1
                                    // convolution on the view, staging a quarter of the pixels)
@@ -127,9 +130,10 @@ __device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NPL]) {
 
 // The LDS-staged weight tile kernel (rounds 2-3), kept as it was for the geometries where it is the faster one; the
 // generalised kernel below adds the register-fed weight path (RF) and the diagnostic builds.
-template <int NPL, int MF, bool SPLIT>
+template <int NPL, int MF, bool SPLIT, bool CR = false>
 __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_v1_kernel(const IgemmParams p) {
   static_assert(SPLIT || NPL == 1, "bf16 input has a single plane");
+  static_assert(!CR || (NPL == 1 && !SPLIT), "chunk-resident weights: bf16 tensors only");
   auto stamp = [](const int) {};
   constexpr int MAXPF = max_prefetch(MF);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -268,10 +272,21 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_v1_kernel(cons
 
   const int nchunks = p.Cip / KC, nsteps = nchunks * p.ntaps;
   __syncthreads();  // zero fill complete
+  // Chunk-resident weights (bf16 tensors): a step of the loop below is 16 MFMAs per wave (256 cycles) behind a weight
+  // tile commit and a barrier — 16-20 % MFMA-busy, 62 % of the bf16 round.  With a single plane the weight tiles of ALL
+  // taps of a (segment, chunk) fit beside the input tile (9 x 4 KB), so they are staged together with it and the taps
+  // run back to back: two barriers per chunk instead of one or two per tap.
+  constexpr int CRT = 9;
+  constexpr bool cr = CR;
   if (nsteps > 0) {
     a_stage_sync(0, 0, p.seg_goff[0]);
+    if (cr) {
+      for (int j = 0; j < p.seg_begin[1] - p.seg_begin[0]; ++j)
+        *reinterpret_cast<u32x4*>(B_lds + j * b_plane + b_dst) = b_load(p.tap_w[p.seg_begin[0] + j], 0, 0);
+    } else {
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q, 0);
+      for (int q = 0; q < NPL; ++q) b_store(b_load(p.tap_w[0], 0, q), q, 0);
+    }
   }
   __syncthreads();
 
@@ -288,7 +303,63 @@ __global__ __launch_bounds__(256, wgs_per_cu(MF)) void conv_igemm_v1_kernel(cons
   const int lane_toff = p.tap_off[lane < MAXTAPS ? lane : 0], lane_tw = p.tap_w[lane < MAXTAPS ? lane : 0];
   int seg_lo = p.seg_begin[0], seg_hi = p.seg_begin[1];  // taps of segment g (kept in registers: a kernel-argument
                                                          // load per step shows in the short steps of the bf16 kernels)
-  for (int ks = 0; ks < nsteps; ++ks) {
+  if constexpr (CR) {
+    if (nsteps > 0) {
+      for (;;) {
+        int cn = c + 1, gn = g;
+        if (cn == nchunks) { cn = 0; gn = g + 1; }
+        const bool more = gn < p.nseg;
+        int nlo = seg_lo, nhi = seg_hi;
+        long goff_next = goff_cur;
+        if (more && gn != g) { nlo = seg_hi; nhi = p.seg_begin[gn + 1]; goff_next = p.seg_goff[gn]; }
+        // 1. global loads of the next (segment, chunk): its weight tiles and its input tile
+        u32x4 breg[CRT];
+        u32x4 areg[MAXPF];
+        if (more) {
+#pragma unroll
+          for (int j = 0; j < CRT; ++j) {
+            breg[j] = u32x4{0, 0, 0, 0};
+            if (nlo + j < nhi) breg[j] = b_load(__builtin_amdgcn_readlane(lane_tw, nlo + j), cn * KC, 0);
+          }
+#pragma unroll
+          for (int j = 0; j < MAXPF; ++j) {
+            areg[j] = u32x4{0, 0, 0, 0};
+            if (j < p.npass) areg[j] = a_load(a_desc(j, goff_next), cn * KC);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // 2. the taps of (segment g, chunk c), no barrier between them
+        for (int tt = seg_lo; tt < seg_hi; ++tt) {
+          const int toff = __builtin_amdgcn_readlane(lane_toff, tt);
+          const unsigned char* Bb = Bb0 + (tt - seg_lo) * b_plane;
+          bf16x8 wf[4];
+#pragma unroll
+          for (int cf = 0; cf < 4; ++cf) wf[cf] = *reinterpret_cast<const bf16x8*>(Bb + cf * 1024);
+#pragma unroll
+          for (int pf = 0; pf < MF; ++pf) {
+            const int sl = a_slot[pf] + toff;
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(A_lds + sl * 64 + ((kg * 16) ^ swz(sl)));
+#pragma unroll
+            for (int cf = 0; cf < 4; ++cf)
+              acc[pf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cf], af, acc[pf][cf], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!more) break;
+        __syncthreads();  // every wave has read this chunk's fragments
+#pragma unroll
+        for (int j = 0; j < CRT; ++j)
+          if (nlo + j < nhi) *reinterpret_cast<u32x4*>(B_lds + j * b_plane + b_dst) = breg[j];
+#pragma unroll
+        for (int j = 0; j < MAXPF; ++j)
+          if (j < p.npass) a_store(a_desc(j, goff_next), areg[j]);
+        a_stage_sync(MAXPF, cn * KC, goff_next);
+        __syncthreads();
+        g = gn; c = cn; seg_lo = nlo; seg_hi = nhi; goff_cur = goff_next;
+      }
+    }
+  }
+  for (int ks = 0; ks < (CR ? 0 : nsteps); ++ks) {
     int tn = t + 1, cn = c, gn = g;
     if (tn == seg_hi) {
       tn = seg_lo; cn = c + 1;
@@ -1067,6 +1138,7 @@ int plan(IgemmParams& p, int npl, const int* ay, const int* ax, bool rf) {
       long lds = (long)npl * q.NS * 64 + (rf ? 0L : 2L * npl * BN * 64);
       q.bdouble = rf ? 0 : 1;
       if (!rf && (lds > LDS_TOTAL / wgs_per_cu(mf) || no_bdouble())) { lds -= (long)npl * BN * 64; q.bdouble = 0; }
+      if (!rf && p.cr_taps > 0) { lds = (long)q.NS * 64 + (long)p.cr_taps * BN * 64; q.bdouble = 0; }  // (npl = 1)
       q.region_px = q.TI * q.IR * p.Wi;
       const bool fits = lds <= LDS_TOTAL / wgs_per_cu(mf) && q.region_px < (1 << 20) && p.Wi < 4096 && q.IR * p.Wi < 4096 * 64;
       if (fits) {
@@ -1128,7 +1200,8 @@ void launch1(const IgemmParams& p, int grid, size_t lds, hipStream_t st) {
 
 template <int NPL, int MF, bool SPLIT>
 int launch(const IgemmParams& p, hipStream_t st, bool rf) {
-  const size_t lds = (size_t)NPL * p.NS * 64 + (rf ? 0 : (size_t)(p.bdouble ? 2 : 1) * NPL * BN * 64);
+  size_t lds = (size_t)NPL * p.NS * 64 + (rf ? 0 : (size_t)(p.bdouble ? 2 : 1) * NPL * BN * 64);
+  if (!rf && p.cr_taps > 0) lds = (size_t)p.NS * 64 + (size_t)p.cr_taps * BN * 64;
   const int blocks = p.n_mtiles * p.n_ntiles;
   const int grid = (blocks + 7) / 8 * 8;
   if constexpr (NPL == 3 && MF >= 2 && SPLIT) {
@@ -1141,6 +1214,18 @@ int launch(const IgemmParams& p, hipStream_t st, bool rf) {
     }
   }
   if (rf) { launch1<NPL, MF, SPLIT, 0, true>(p, grid, lds, st); return 0; }
+  if constexpr (NPL == 1 && !SPLIT) {
+    if (p.cr_taps > 0) {
+      static bool attr_cr = false;
+      if (!attr_cr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_v1_kernel<1, MF, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / wgs_per_cu(MF));
+        attr_cr = true;
+      }
+      hipLaunchKernelGGL((conv_igemm_v1_kernel<1, MF, false, true>), dim3(grid), dim3(256), lds, st, p);
+      return 0;
+    }
+  }
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_v1_kernel<NPL, MF, SPLIT>),
@@ -1192,8 +1277,17 @@ void build_perm(IgemmParams& p, int mf) {
 
 int dispatch(IgemmParams& p, int npl, const int* ay, const int* ax, hipStream_t st) {
   bool rf = false;
-  const int mf = choose(p, npl, ay, ax, rf);
+  p.cr_taps = 0;
+  if (npl == 1) {  // bf16 tensors: chunk-resident weights where a segment has at most 9 taps (BLADES_IGEMM_CR=0: off)
+    int tmax = p.nseg == 0 ? p.ntaps : 0;
+    for (int g = 0; g < p.nseg; ++g) tmax = std::max(tmax, p.seg_begin[g + 1] - p.seg_begin[g]);
+    const char* e = getenv("BLADES_IGEMM_CR");
+    if (tmax >= 1 && tmax <= 9 && !(e && atoi(e) == 0)) p.cr_taps = tmax;
+  }
+  int mf = choose(p, npl, ay, ax, rf);
+  if (mf == 0 && p.cr_taps > 0) { p.cr_taps = 0; mf = choose(p, npl, ay, ax, rf); }
   if (mf == 0) return 3;
+  if (rf) p.cr_taps = 0;
   const int PIXPP = npl == 1 ? 64 : 32;
   p.npass = (p.region_px + PIXPP - 1) / PIXPP;
   p.inv_ws = 1.0f / p.Ws; p.inv_tr = 1.0f / p.TR; p.inv_wi = 1.0f / p.Wi; p.inv_irwi = 1.0f / (p.IR * p.Wi);

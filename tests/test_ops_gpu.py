@@ -307,11 +307,15 @@ def test_fused_engine_gpu_matches_fp32_reference(dev, tmp_path, amp):
 
 
 def _igemm_path(monkeypatch, path):
-    """Environment of a conv_igemm variant: "rf" / "lds" weight path, optional "-mfN" pixel fragments per wave."""
-    for k in ("BLADES_IGEMM_RF", "BLADES_IGEMM_MF"):
+    """Environment of a conv_igemm variant: "rf" / "lds" weight path, optional "-mfN" pixel fragments per wave,
+    optional "-nocr"."""
+    for k in ("BLADES_IGEMM_RF", "BLADES_IGEMM_MF", "BLADES_IGEMM_CR"):
         monkeypatch.delenv(k, raising=False)
     if path == "default":
         return
+    if path.endswith("-nocr"):  # bf16 tensors: a weight tile per tap instead of the chunk-resident tiles
+        monkeypatch.setenv("BLADES_IGEMM_CR", "0")
+        path = path[:-5]
     kind, _, mf = path.partition("-mf")
     monkeypatch.setenv("BLADES_IGEMM_RF", "1" if kind == "rf" else "0")
     if mf:
@@ -450,7 +454,7 @@ def test_conv_wgrad_kernel(dev, Kc, B, Cin, Cout, H, ks, stride, pad, npl):
     (2, 16, 12, 12, 16, 3, 3, 0),
 ])
 @pytest.mark.parametrize("npl", [3, 2, 1])
-@pytest.mark.parametrize("path", ["default", "rf", "rf-mf4", "lds-mf4", "rf-mf2"])
+@pytest.mark.parametrize("path", ["default", "rf", "rf-mf4", "lds-mf4", "rf-mf2", "lds-mf4-nocr"])
 def test_conv_igemm_kernel(dev, monkeypatch, N, Ci, H, W, Co, k, s, p, npl, path):
     """Own forward / data-gradient convolution (ops/csrc/conv_igemm.hip) against an fp64 convolution — on the weight
     path and tile size the planner picks for these small problems ("default": mostly 64-pixel tiles, LDS-staged
