@@ -22,20 +22,19 @@
 namespace {
 
 constexpr int KMAX = 128;
-constexpr int TPB = 256;
+constexpr int TPB = 256;  // four waves: block_sum adds four wave sums
 
+// fixed-order sum over the 256 threads: butterfly inside each wave (shuffles, no barrier), then the four wave sums in
+// wave order through LDS — 2 barriers instead of the 10 of an LDS tree (a Weiszfeld iteration has three of these and a
+// solver runs up to a hundred iterations: the barriers were most of its time)
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T* red) {
-  // fixed-order tree over the 256 threads
-  red[threadIdx.x] = v;
-  __syncthreads();
 #pragma unroll
-  for (int s = TPB / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  const T r = red[0];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
+  const T r = ((red[0] + red[1]) + red[2]) + red[3];
+  __syncthreads();  // (red is reused by the next reduction)
   return r;
 }
 
@@ -128,13 +127,11 @@ __global__ __launch_bounds__(TPB) void minmax_bisect_kernel(const float* __restr
     const float two_mid = __fmul_rn(2.f, mid), mid2c = __fmul_rn(__fmul_rn(mid, mid), c);
     float m = 0.f;  // = clamp_min(., 0) of the maximum
     for (int i = t; i < n; i += TPB) m = fmaxf(m, __fadd_rn(__fadd_rn(a[i], -__fmul_rn(two_mid, b[i])), mid2c));
-    red[t] = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((t & 63) == 0) red[t >> 6] = m;
     __syncthreads();
-    for (int s = TPB / 2; s > 0; s >>= 1) {
-      if (t < s) red[t] = fmaxf(red[t], red[t + s]);
-      __syncthreads();
-    }
-    const bool ok = sqrtf(red[0]) < thr;
+    const bool ok = sqrtf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))) < thr;
     __syncthreads();
     if (ok) low = mid; else high = mid;
     hi_f = lo_f + (hi_f - lo_f) * 0.5f;
