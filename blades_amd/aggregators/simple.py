@@ -172,14 +172,14 @@ class DnC(Aggregator):
                  power_iters: int = 8, seed: int = 0, sampler: str = "auto"):
         super().__init__()
         if sampler not in ("auto", "numpy"):
-            raise ValueError("DnC: sampler must be 'auto' (GPU draw for large draws on GPU tensors) or 'numpy'")
+            raise ValueError("DnC: sampler must be 'auto' (keyed permutation, ops.sample_distinct) or 'numpy' "
+                             "(numpy.random.Generator.choice on the host)")
         self.sampler = sampler
         self.num_byzantine = num_byzantine
         self.sub_dim = sub_dim
         self.num_iters = num_iters
         self.fliter_frac = filter_frac  # (sic) attribute name of the reference
         self.power_iters = power_iters
-        self._gen = None
         self._seed = seed
         self._calls = 0
 
@@ -196,37 +196,27 @@ class DnC(Aggregator):
         idx = rng.choice(d_total, size=n, replace=False, shuffle=False)
         return torch.from_numpy(idx.astype(np.int64)).to(device, non_blocking=True)
 
-    def _sample_columns_device(self, d_total: int, device, iters: int):
-        """All iterations' index sets ``[iters, n]`` drawn on the GPU, or None when this sampler does not apply
-        (CPU tensors, small or dense draws: the numpy sampler then).  The five host-side draws and uploads of a call
-        were 0.5-1.2 ms of CPU time on 0.7-3 ms rounds of the 60-client configs.
+    def _sample_columns_all(self, d_total: int, device, iters: int):
+        """All iterations' index sets ``[iters, n]``, or None with ``sampler="numpy"`` (the host draw per iteration).
 
-        Sequential rejection in one shot: 2 n uniform draws per iteration (Philox, seeded from (seed, call counter):
-        the same numbers on every rank), the first n distinct values in draw order — exactly a uniform draw without
-        replacement.  With n >= 1024 and D >= 4 n the 2 n draws hold ~1.5 n distinct values (fewer than n is > 20
-        standard deviations away)."""
-        n = min(self.sub_dim, d_total)
-        if self.sampler == "numpy" or device.type != "cuda" or n < 1024 or d_total < 4 * n:
+        Set ``it`` is the image of ``0..n-1`` under a keyed pseudo-random permutation of ``[0, d_total)``
+        (``ops.sample_distinct``: Feistel network + cycle walking, keyed by (seed, call counter, it)) — n distinct
+        coordinates, every one computed independently: one tiny launch on the GPU, the same numbers on the CPU, on every
+        rank and for every layout.  The five host-side draws and uploads of a call were 0.5-1.2 ms of CPU time on
+        0.7-3 ms rounds of the 60-client configs; a rejection draw on the GPU (2 n draws, stable sort, first n distinct)
+        took 0.38 ms of sorting."""
+        if self.sampler == "numpy" or iters < 1:
             return None
-        if self._gen is None or self._gen.device != device:
-            self._gen = torch.Generator(device=device)
-        self._gen.manual_seed(self._seed * 1000003 + self._calls)
+        n = min(self.sub_dim, d_total)
+        idx = ops.sample_distinct(d_total, n, iters, self._seed * 1000003 + self._calls, device)
         self._calls += iters
-        x = torch.randint(0, d_total, (iters, 2 * n), device=device, generator=self._gen)
-        xs, order = torch.sort(x, dim=1, stable=True)  # equal values stay in draw order: the first one is kept
-        fresh_sorted = torch.ones_like(xs, dtype=torch.bool)
-        fresh_sorted[:, 1:] = xs[:, 1:] != xs[:, :-1]
-        fresh = torch.empty_like(fresh_sorted).scatter_(1, order, fresh_sorted)
-        rank = fresh.cumsum(1)  # rank[i, p] = distinct values among draws 0..p
-        want = torch.arange(1, n + 1, device=device).expand(iters, n).contiguous()
-        pos = torch.searchsorted(rank, want).clamp_(max=2 * n - 1)  # position of the j-th distinct value
-        return x.gather(1, pos)
+        return idx
 
     def aggregate(self, U, ctx):
         K = U.shape[0]
         n_keep = K - int(self.fliter_frac * self.num_byzantine)
         keep_mask = torch.zeros(K, dtype=torch.bool, device=U.device)
-        idx_all = self._sample_columns_device(ctx.d_total, U.device, self.num_iters) if self.num_iters > 0 else None
+        idx_all = self._sample_columns_all(ctx.d_total, U.device, self.num_iters)
         if idx_all is not None and not ctx.distributed and K <= ops.smallk_max(U.device):
             # small client counts on one GPU: all iterations at once (one gather, one batched Gram product, one
             # launch for the power iterations) — ~12 launches instead of ~60

@@ -134,6 +134,15 @@ def gram_batched(S):
     return ref.gram_batched(S)
 
 
+def sample_distinct(D, n, iters, seed, device):
+    """``iters`` sets of ``n`` distinct ids in ``[0, D)`` — a keyed pseudo-random permutation of ``[0, D)`` applied to
+    ``0..n-1``; the same numbers on the CPU and on the GPU.  int64 ``[iters, n]`` on ``device``."""
+    device = torch.device(device)
+    if device.type == "cuda" and not _FORCE_REFERENCE:
+        return _h().sample_distinct(D, n, iters, seed, device)
+    return ref.sample_distinct(int(D), int(n), int(iters), int(seed)).to(device)
+
+
 def gather_center_cols(U, idx):
     """Centred column sub-samples ``[iters, K, n]`` of ``U`` at the column ids ``idx[iters, n]``."""
     if _use_hip(_f32c(U)):

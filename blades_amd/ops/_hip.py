@@ -350,6 +350,18 @@ def gram_batched(S):
     return out
 
 
+_sample_distinct = _opt_sig("blades_sample_distinct", [c_long, c_long, c_long, ctypes.c_ulonglong, _P, _P], c_int)
+
+
+def sample_distinct(D: int, n: int, iters: int, seed: int, device):
+    """``iters`` sets of ``n`` distinct column ids in ``[0, D)`` (colgather.hip: keyed Feistel permutation with cycle
+    walking; ops/reference.py::sample_distinct gives the same numbers): int64 ``[iters, n]`` on ``device``."""
+    out = torch.empty(int(iters), int(n), dtype=torch.int64, device=device)
+    if _sample_distinct(int(D), int(n), int(iters), int(seed) & ((1 << 64) - 1), _ptr(out), _stream()) != 0:
+        raise ValueError("sample_distinct: need 1 <= n <= D <= 2^40")
+    return out
+
+
 def gather_center_cols(U, idx):
     """``out[i, k, j] = U[k, idx[i, j]] - mean_k U[k, idx[i, j]]`` (colgather.hip): the centred column sub-samples of
     DnC, ``[iters, K, n]`` fp32 contiguous.  ``idx``: int64 ``[iters, n]`` on the device."""

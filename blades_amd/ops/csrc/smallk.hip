@@ -38,6 +38,9 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
   return r;
 }
 
+// P = 2, 4 or 8 neighbouring lanes share a row of the matrix-vector product (lane `sub` takes columns sub, sub + P, ...;
+// butterfly over the P lanes): a thread per row was a chain of K dependent multiply-adds per step, 80 us for the 72
+// steps of DnC at 60 clients
 __global__ __launch_bounds__(TPB) void power_top_kernel(const float* __restrict__ G, int K, int steps, float* __restrict__ out) {
   extern __shared__ float lds[];
   float* g = lds;                    // [K][K + 1]
@@ -48,16 +51,19 @@ __global__ __launch_bounds__(TPB) void power_top_kernel(const float* __restrict_
   out += (size_t)blockIdx.x * K;
   for (int i = t; i < K * K; i += TPB) g[(i / K) * (K + 1) + (i % K)] = G[i];
   if (t < K) v[t] = 1.0f / sqrtf((float)K) + (float)t * (1e-3f / (float)K);
+  const int P = K <= 32 ? 8 : K <= 64 ? 4 : 2;  // P * K <= 256
+  const int row = t / P, sub = t - row * P;
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     float w = 0.f;
-    if (t < K) {
-      const float* row = g + t * (K + 1);
-      for (int j = 0; j < K; ++j) w += row[j] * v[j];
+    if (row < K) {
+      const float* gr = g + row * (K + 1);
+      for (int j = sub; j < K; j += P) w += gr[j] * v[j];
     }
-    const float n2 = block_sum<float>(w * w, red);  // (barriers inside: every thread has read v)
+    for (int o = 1; o < P; o <<= 1) w += __shfl_xor(w, o);  // (the P lanes of a row are neighbours inside one wave)
+    const float n2 = block_sum<float>(row < K && sub == 0 ? w * w : 0.f, red);  // (barriers inside: every thread has read v)
     const float nrm = fmaxf(sqrtf(n2), 1e-30f);
-    if (t < K) v[t] = w / nrm;
+    if (row < K && sub == 0) v[row] = w / nrm;
     __syncthreads();
   }
   if (t < K) out[t] = v[t];

@@ -106,6 +106,61 @@ def gram_batched(S: torch.Tensor) -> torch.Tensor:
     return torch.bmm(S, S.transpose(1, 2))
 
 
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(z: int) -> int:
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def sample_distinct(D: int, n: int, iters: int, seed: int) -> torch.Tensor:
+    """``iters`` sets of ``n`` distinct ids in ``[0, D)``: set ``it`` is the image of ``0..n-1`` under a keyed
+    pseudo-random permutation of ``[0, D)`` (balanced Feistel network, eight rounds, cycle walking).  The same numbers as
+    ops/csrc/colgather.hip::sample_distinct_kernel, bit for bit.  int64 ``[iters, n]``."""
+    import numpy as np
+
+    if not (1 <= n <= D <= (1 << 40) and iters >= 1):
+        raise ValueError("sample_distinct: need 1 <= n <= D <= 2^40")
+    b = 2
+    while (1 << b) < D:
+        b += 1
+    b += b & 1
+    h = b // 2
+    mask = np.uint32((1 << h) - 1)
+    out = np.empty((iters, n), dtype=np.int64)
+
+    def mix32(x):
+        x = x ^ (x >> np.uint32(16))
+        x = x * np.uint32(0x85EBCA6B)
+        x = x ^ (x >> np.uint32(13))
+        x = x * np.uint32(0xC2B2AE35)
+        return x ^ (x >> np.uint32(16))
+
+    with np.errstate(over="ignore"):
+        for it in range(iters):
+            keys = [np.uint32(_splitmix64((seed + 0x632BE59BD9B4E019 * (it * 8 + r + 1)) & _M64) & 0xFFFFFFFF)
+                    for r in range(8)]
+            x = np.arange(n, dtype=np.uint64)
+            todo = np.ones(n, dtype=bool)
+            for _ in range(512):
+                cur = x[todo]
+                L = (cur >> np.uint64(h)).astype(np.uint32)
+                R = cur.astype(np.uint32) & mask
+                for r in range(8):
+                    L, R = R, L ^ (mix32(R + keys[r]) & mask)
+                cur = (L.astype(np.uint64) << np.uint64(h)) | R.astype(np.uint64)
+                x[todo] = cur
+                todo = x >= np.uint64(D)
+                if not todo.any():
+                    break
+            x = np.where(todo, x % np.uint64(D), x)
+            out[it] = x.astype(np.int64)
+    return torch.from_numpy(out)
+
+
 def gather_center_cols(U: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """``out[i, k, j] = U[k, idx[i, j]] - mean_k U[k, idx[i, j]]``: ``[iters, K, n]``."""
     iters, n = idx.shape

@@ -207,3 +207,30 @@ def test_call_does_not_modify_the_callers_tensor(name):
     keep = U.clone()
     getattr(A, name)()(U)
     assert torch.equal(U, keep)
+
+
+def test_sample_distinct_is_a_draw_without_replacement():
+    """ops.sample_distinct (DnC's coordinate draw; reference: np.random.choice(d, sub_dim, replace=False)): n distinct
+    ids per set from a keyed permutation of [0, D); n = D gives a permutation; sets and seeds differ; roughly uniform."""
+    from blades_amd import ops
+
+    p = ops.sample_distinct(1000, 1000, 3, 7, "cpu")
+    assert p.shape == (3, 1000) and p.dtype == torch.int64
+    for row in p:
+        assert torch.equal(row.sort().values, torch.arange(1000))
+    assert not torch.equal(p[0], p[1]) and not torch.equal(p[0], torch.arange(1000))
+    assert torch.equal(p, ops.sample_distinct(1000, 1000, 3, 7, "cpu"))
+    assert not torch.equal(p, ops.sample_distinct(1000, 1000, 3, 8, "cpu"))
+    D, n = 136074, 10000
+    s = ops.sample_distinct(D, n, 5, 42, "cpu")
+    assert all(r.unique().numel() == n for r in s) and int(s.min()) >= 0 and int(s.max()) < D
+    hist = torch.histc(s.float(), bins=20, min=0, max=D)
+    expect = 5 * n / 20
+    assert float((hist - expect).abs().max()) < 5 * expect ** 0.5
+    # position j of a set is not correlated with its id (a sorted or strided prefix would be)
+    r = torch.corrcoef(torch.stack([torch.arange(n).double(), s[0].double()]))[0, 1]
+    assert abs(float(r)) < 0.05
+    # overlap of two sets is what independent draws give: n^2 / D expected common ids
+    common = len(set(s[0].tolist()) & set(s[1].tolist()))
+    assert abs(common - n * n / D) < 6 * (n * n / D) ** 0.5
+    assert ops.sample_distinct(1, 1, 2, 0, "cpu").tolist() == [[0], [0]]

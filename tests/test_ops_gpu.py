@@ -898,10 +898,12 @@ def test_aggregators_gpu_match_cpu(dev, name, kw):
 
 
 def test_dnc_device_sampler_and_batched_iterations(dev):
-    """DnC on GPU tensors (aggregators/simple.py): index sets drawn on the device (distinct, in range, a function of
-    (seed, call counter) only) and, for K <= 128 on one GPU, all iterations in one batch — same kept set as the
-    per-iteration loop on the same index sets."""
+    """DnC on GPU tensors (aggregators/simple.py): index sets from the keyed permutation kernel (distinct, in range, a
+    function of (seed, call counter) only, bit-identical to the CPU form) and, for K <= 128 on one GPU, all iterations
+    in one batch — same kept set as the per-iteration loop on the same index sets."""
     from blades_amd import aggregators as A
+    from blades_amd import ops as ops_mod
+    from blades_amd.ops import reference as ref_mod
     from blades_amd.parallel.context import local_context
 
     K, D, f = 30, 60011, 6
@@ -911,27 +913,34 @@ def test_dnc_device_sampler_and_batched_iterations(dev):
     U = U.to(dev)
     ctx = local_context(D)
     a = A.DnC(num_byzantine=f, sub_dim=2000, num_iters=5, seed=11)
-    idx = a._sample_columns_device(D, U.device, 5)
-    assert idx.shape == (5, 2000) and idx.dtype == torch.int64
+    idx = a._sample_columns_all(D, U.device, 5)
+    assert idx.shape == (5, 2000) and idx.dtype == torch.int64 and idx.is_cuda
     assert int(idx.min()) >= 0 and int(idx.max()) < D
     for row in idx.cpu():
         assert row.unique().numel() == 2000
     assert not torch.equal(idx[0], idx[1])
     b = A.DnC(num_byzantine=f, sub_dim=2000, num_iters=5, seed=11)
-    assert torch.equal(idx, b._sample_columns_device(D, U.device, 5))       # same (seed, calls): same draw
-    assert not torch.equal(idx, b._sample_columns_device(D, U.device, 5))   # the call counter moved on
+    assert torch.equal(idx, b._sample_columns_all(D, U.device, 5))       # same (seed, calls): same draw
+    assert not torch.equal(idx, b._sample_columns_all(D, U.device, 5))   # the call counter moved on
     assert a.state_dict() == {"calls": 5}
-    # uniformity, roughly: mean of the drawn ids is D / 2 within 5 standard errors
+    # the CPU form gives the same numbers (every rank, both devices, every layout draw the same sets)
+    c = A.DnC(num_byzantine=f, sub_dim=2000, num_iters=5, seed=11)
+    assert torch.equal(idx.cpu(), c._sample_columns_all(D, torch.device("cpu"), 5))
+    for Dx, nx, it, seed in ((1, 1, 2, 0), (2, 2, 1, 5), (3, 3, 3, 1), (1000, 1000, 2, 9), (136074, 10000, 5, 123456789),
+                             (11173962, 10000, 5, 2 ** 63 + 17), (2 ** 33 + 5, 777, 2, 3)):
+        got = ops_mod.sample_distinct(Dx, nx, it, seed, dev).cpu()
+        exp = ref_mod.sample_distinct(Dx, nx, it, seed)
+        assert torch.equal(got, exp), (Dx, nx)
+        assert all(r.unique().numel() == nx for r in got) and int(got.min()) >= 0 and int(got.max()) < Dx
+    # uniformity, roughly: mean of the drawn ids is D / 2 within 5 standard errors; every tenth of the range gets its share
     se = D / (12 ** 0.5) / (5 * 2000) ** 0.5
     assert abs(float(idx.double().mean()) - (D - 1) / 2) < 5 * se
-    # small or dense draws and sampler="numpy" stay on the host sampler
-    assert A.DnC(num_byzantine=f, sub_dim=500)._sample_columns_device(D, U.device, 5) is None
-    assert A.DnC(num_byzantine=f, sub_dim=20000)._sample_columns_device(D, U.device, 5) is None
-    assert A.DnC(num_byzantine=f, sub_dim=2000, sampler="numpy")._sample_columns_device(D, U.device, 5) is None
+    hist = torch.histc(idx.float().cpu(), bins=10, min=0, max=D)
+    assert float((hist - 1000).abs().max()) < 5 * (1000 * 0.9) ** 0.5
+    assert A.DnC(num_byzantine=f, sub_dim=2000, sampler="numpy")._sample_columns_all(D, U.device, 5) is None
 
     # the two kernels of the batched path against their tensor forms
-    from blades_amd import ops
-    from blades_amd.ops import reference as ref
+    ops, ref = ops_mod, ref_mod
     Uv = torch.randn(K, D + 5, device=dev)[:, 3:D + 3]  # odd row stride, unaligned start
     S = ops.gather_center_cols(Uv, idx)
     assert S.shape == (5, K, 2000) and S.is_contiguous()

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out; rm -f gpurun_out/run49.log
-timeout -k 10 300 python -u -m pytest tests/test_ops_gpu.py tests/test_engine_gpu.py -x -q --timeout 120 --timeout-method thread -k "small_client or dnc or aggregators_gpu or adversaries_gpu or minmax or MinMax" > gpurun_out/run49_tests.log 2>&1 || { tail -40 gpurun_out/run49_tests.log; exit 1; }
+timeout -k 10 300 python -u -m pytest tests/test_ops_gpu.py tests/test_engine_gpu.py -x -q --timeout 120 --timeout-method thread -k "small_client or dnc or aggregators_gpu or adversaries_gpu or minmax or MinMax or gram" > gpurun_out/run49_tests.log 2>&1 || { tail -40 gpurun_out/run49_tests.log; exit 1; }
 tail -2 gpurun_out/run49_tests.log
 for cfg in "mnist mlp" "fashionmnist cnn"; do
   set -- $cfg
