@@ -129,22 +129,35 @@ class Server(LearningRateSchedule):
             agg = self._aggregator.aggregate(U, self.ctx)  # in place on the engine's matrix
         else:
             agg = self._aggregator(U, self.ctx)  # [Dl]; __call__ copies a caller-owned tensor before clipping rows
+        bad = None
         if self.nan_guard:
             # A non-finite aggregate (diverged clients, an attack the defence let
             # through) would poison theta for good: skip the step instead.  Decided
             # on the device, no host sync; all ranks agree through the all-reduce.
-            bad = (~torch.isfinite(agg).all()).float()
-            if self.ctx.distributed:
-                self.ctx.all_reduce(bad)
-            agg = torch.where(bad > 0, torch.zeros_like(agg), agg)
-            self.skipped_steps = self.skipped_steps + bad.clamp(max=1)
-        self.apply_aggregate(agg)
+            lo = self.ctx.col_offset
+            if ops.guarded_step_available(self.theta[lo: lo + self.Dl], agg) and self.skipped_steps.dtype == torch.float32:
+                # one flag kernel, and the step kernel reads the flag (ops/csrc/optim.hip)
+                bad = ops.nonfinite_flag(agg)
+                if self.ctx.distributed:
+                    self.ctx.all_reduce(bad)
+            else:
+                flag = (~torch.isfinite(agg).all()).float()
+                if self.ctx.distributed:
+                    self.ctx.all_reduce(flag)
+                agg = torch.where(flag > 0, torch.zeros_like(agg), agg)
+                self.skipped_steps = self.skipped_steps + flag.clamp(max=1)
+        self.apply_aggregate(agg, bad)
 
-    def apply_aggregate(self, agg: Tensor) -> None:
+    def apply_aggregate(self, agg: Tensor, bad: Optional[Tensor] = None) -> None:
+        """``bad``: fp32 device scalar, > 0 = take this step with a zero aggregate and count it as skipped."""
         lo = self.ctx.col_offset
         sl = self.theta[lo: lo + self.Dl]
         buf = self.momentum_buf if self.momentum_buf is not None else sl
-        ops.server_step_(sl, buf, agg.to(sl.dtype), self.cur_lr, self.momentum, self._steps == 0)
+        if bad is not None:
+            ops.server_step_guarded_(sl, buf, agg, self.cur_lr, self.momentum, self._steps == 0, bad,
+                                     self.skipped_steps)
+        else:
+            ops.server_step_(sl, buf, agg.to(sl.dtype), self.cur_lr, self.momentum, self._steps == 0)
         self._steps += 1
         if self.ctx.distributed:
             dist.all_gather_into_tensor(self.theta, sl.clone(), group=self.ctx.group)

@@ -372,6 +372,35 @@ class ClientEngine:
         # ResNet-18 headline no — there the GPU is saturated and a graph would only pin activation memory)
         return len(self._train_rows) * self.B * self.D <= 5e10
 
+    def _begin_round_planes(self):
+        """``fused.begin_round()`` — one weight-plane launch per convolution / Linear layer — as a HIP graph where the
+        round itself is graphed: on the MLP these six eager launches with their gaps were 0.2 ms of a 0.65 ms round
+        (timeline in profiles/r3_small_round_timeline_mlp_dnc.txt).  The graph reads the weights and writes the planes
+        by address: it is re-captured when a weight tensor has moved."""
+        if not self._graphs_wanted() or os.environ.get("BLADES_ROUND_PLANES", "1") == "0":
+            self.fused.begin_round()
+            return
+        ent = self.__dict__.setdefault("_planes_graph", {"visits": 0, "graph": None, "key": None})
+        key = tuple(p.data_ptr() for p in self.fused.template.parameters()) + (self.fused.sink.npl,)
+        if ent["graph"] is not None and ent["key"] == key:
+            ent["graph"].replay()
+            self.fused.sink.planes_valid = True
+            return
+        ent["visits"] += 1
+        self.fused.begin_round()  # eager: allocates the plane buffers on the first visits
+        if ent["visits"] <= 2 or ent.get("failed"):
+            return
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                self.fused.begin_round()
+        except Exception as e:  # noqa: BLE001 — not capturable: stay eager
+            ent["failed"] = repr(e)
+            torch.cuda.synchronize()
+            self.fused.begin_round()
+            return
+        ent.update(graph=g, key=key)  # (capture does not execute: the eager call above produced this round's planes)
+
     def _graphed_chunk(self, rows, srows):
         """Replays (capturing on the third visit) the HIP graph of this chunk; ``None`` = not graphable."""
         tf = self.dataset.train_transform
@@ -717,7 +746,7 @@ class ClientEngine:
         if self.fused is not None and self.nb == 1:
             # theta does not change until the server step: the convolution weights are split into their operand
             # planes once, here, instead of once per chunk and launch
-            self.fused.begin_round()
+            self._begin_round_planes()
         # Chunks alternate between `n_streams` HIP streams (closes launch gaps and kernel tails, see __init__).
         n_streams = self.n_streams if (dev.type == "cuda" and not late) else 1
         if n_streams > 1 and self._graphs_wanted():

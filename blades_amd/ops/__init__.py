@@ -180,6 +180,20 @@ def server_step_(theta, buf, agg, lr, momentum, first):
     return ref.server_step_(theta, buf, agg, lr, momentum, first)
 
 
+def guarded_step_available(theta, agg) -> bool:
+    """The fused non-finite guard + server step (ops/csrc/optim.hip) applies: fp32 contiguous CUDA vectors."""
+    return (theta.is_cuda and agg.is_cuda and not _FORCE_REFERENCE and theta.dtype == torch.float32
+            and agg.dtype == torch.float32 and theta.is_contiguous() and agg.is_contiguous())
+
+
+def nonfinite_flag(x):
+    return _h().nonfinite_flag(x)
+
+
+def server_step_guarded_(theta, buf, agg, lr, momentum, first, bad, skipped):
+    return _h().server_step_guarded_(theta, buf, agg, float(lr), float(momentum), bool(first), bad, skipped)
+
+
 def client_sgd_step_(W, G, M, lr, momentum, first, gscale=None):
     if W.is_cuda and not _FORCE_REFERENCE:
         return _h().client_sgd_step_(W, G, M, float(lr), float(momentum), bool(first), gscale)

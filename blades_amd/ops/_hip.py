@@ -453,6 +453,34 @@ def server_step_(theta, buf, agg, lr, momentum, first):
     return theta
 
 
+_nonfinite_flag = _opt_sig("blades_nonfinite_flag", [_P, c_long, _P, _P], None)
+_server_step_guarded = _opt_sig("blades_server_step_guarded", [_P, _P, _P, c_long, c_float, c_float, c_int, _P, _P, _P], None)
+
+
+def nonfinite_flag(x):
+    """fp32 ``[1]`` tensor: 1 when ``x`` (contiguous fp32) holds an inf / nan, else 0 — decided on the device."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise ValueError("nonfinite_flag: need a contiguous fp32 CUDA tensor")
+    flag = torch.empty(1, device=x.device, dtype=torch.float32)
+    _nonfinite_flag(_ptr(x), x.numel(), _ptr(flag), _stream())
+    return flag
+
+
+def server_step_guarded_(theta, buf, agg, lr, momentum, first, bad, skipped):
+    """``server_step_`` that treats the aggregate as zero when ``bad[0] > 0`` and then adds 1 to ``skipped`` (fp32
+    device scalars): the non-finite guard without host sync and without the eight ATen launches of its tensor form."""
+    n = theta.numel()
+    for t in (theta, agg) + ((buf,) if momentum != 0.0 else ()):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+            raise ValueError("server_step_guarded_: need contiguous fp32 CUDA vectors of equal length")
+    for t in (bad, skipped):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
+            raise ValueError("server_step_guarded_: bad / skipped are fp32 CUDA scalars")
+    _server_step_guarded(_ptr(theta), _ptr(buf if momentum != 0.0 else theta), _ptr(agg), n, lr, momentum, int(first),
+                         _ptr(bad), _ptr(skipped), _stream())
+    return theta
+
+
 def client_sgd_step_(W, G, M, lr, momentum, first, gscale=None):
     Kc, D, ldw = _chk_matrix(W)
     Kg, Dg, ldg = _chk_matrix(G)

@@ -365,3 +365,46 @@ def test_dropout_masks_do_not_depend_on_chunk_streams(tmp_path):
     assert e1.n_streams == 1 and e3.n_streams == 3
     assert l1 == l3
     assert torch.equal(U1, U3)
+
+
+def test_round_plane_graph_follows_the_weights(tmp_path):
+    """The per-round weight-plane launches run as a HIP graph in graphed rounds (trainer._begin_round_planes): with a
+    server step between the rounds the replayed graph must split the *new* weights — graphed and eager runs stay
+    bitwise equal over rounds in which theta moves."""
+    U_e, loss_e, eng_e = _run(tmp_path, "0", "cifar10", "resnet", "ALIEAdversary", rounds=7, server_lr=0.5)
+    U_g, loss_g, eng_g = _run(tmp_path, "1", "cifar10", "resnet", "ALIEAdversary", rounds=7, server_lr=0.5)
+    assert eng_e.__dict__.get("_planes_graph") is None
+    pg = eng_g.__dict__.get("_planes_graph")
+    assert pg is not None and pg["graph"] is not None and not pg.get("failed")
+    assert loss_g == loss_e and len(set(loss_e)) > 3  # the weights moved
+    assert torch.equal(U_g, U_e)
+
+
+def test_server_nonfinite_guard_on_gpu(tmp_path):
+    """algorithms/server.py on the GPU: the flag kernel + guarded step (ops/csrc/optim.hip) skip the round whose
+    aggregate holds a NaN, count it, and leave theta and later rounds intact (CPU form: tests/test_fault_tolerance.py)."""
+    from blades_amd.algorithms.fedavg import FedavgConfig
+
+    os.environ["BLADES_SYNTHETIC_DATA"] = "1"
+    for momentum in (0.0, 0.9):
+        cfg = (FedavgConfig().resources(num_gpus_for_driver=1)
+               .data(dataset_config={"type": "mnist", "num_clients": 6, "num_classes": 10, "train_batch_size": 8,
+                                     "n_train": 120, "n_test": 48, "data_root": str(tmp_path), "use_cache": False})
+               .training(global_model="mlp", server_config={"aggregator": {"type": "Mean"},
+                                                            "optimizer": {"lr": 0.1, "momentum": momentum}})
+               .client(client_config={"lr": 1.0})
+               .evaluation(evaluation_interval=0)
+               .fault_tolerance(fault_injection={"round": 2, "kind": "nan_row", "row": 1}))
+        cfg.seed = 3
+        algo = cfg.build()
+        algo.train()
+        theta1 = algo.server.theta.clone()
+        algo.train()  # the aggregate is NaN
+        assert float(algo.server.skipped_steps) == 1.0
+        if momentum == 0.0:
+            assert torch.equal(algo.server.theta, theta1)
+        else:  # a zero aggregate still applies the momentum buffer
+            assert torch.isfinite(algo.server.theta).all() and not torch.equal(algo.server.theta, theta1)
+        algo.train()
+        assert torch.isfinite(algo.server.theta).all() and float(algo.server.skipped_steps) == 1.0
+        assert not torch.equal(algo.server.theta, theta1)

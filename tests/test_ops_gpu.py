@@ -169,6 +169,28 @@ def test_optimizer_steps(dev):
             ops.server_step_(a, ba, agg, 0.1, mu, first)
             ref.server_step_(b, bb, agg, 0.1, mu, first)
         torch.testing.assert_close(a, b)
+    # the non-finite guard of the server step (algorithms/server.py): flag kernel + guarded step
+    assert float(ops.nonfinite_flag(agg)) == 0.0 and float(ops.nonfinite_flag(torch.zeros(0, device=dev))) == 0.0
+    for pos, val in ((0, float("nan")), (n - 1, float("inf")), (n // 2, float("-inf"))):
+        x = agg.clone()
+        x[pos] = val
+        assert float(ops.nonfinite_flag(x)) == 1.0
+    big = torch.full((5,), 3.4e38, device=dev)
+    assert float(ops.nonfinite_flag(big)) == 0.0
+    for mu in (0.0, 0.9):
+        for badv in (0.0, 2.0):
+            a, b = th.clone(), th.clone()
+            ba, bb = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+            skipped = torch.zeros((), device=dev)
+            bad = torch.full((1,), badv, device=dev)
+            poisoned = agg.clone()
+            if badv:
+                poisoned[17] = float("nan")
+            for first in (True, False):
+                ops.server_step_guarded_(a, ba, poisoned, 0.1, mu, first, bad, skipped)
+                ref.server_step_(b, bb, torch.zeros_like(agg) if badv else agg, 0.1, mu, first)
+            torch.testing.assert_close(a, b)
+            assert bool(torch.isfinite(a).all()) and float(skipped) == (2.0 if badv else 0.0)
     Kc, D = 7, 3001
     for mu in (0.0, 0.5):
         W = torch.randn(Kc, D, device=dev)
