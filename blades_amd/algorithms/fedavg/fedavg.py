@@ -251,8 +251,14 @@ class Fedavg(Algorithm):
         with T("aggregate_and_step"):
             server_return = self.server.step(U, global_vars, owned=True)
         self._check_replicas()
-        stats = torch.stack([loss_sum, loss_cnt]).tolist()  # the round's single host sync
+        pack = torch.stack([loss_sum, loss_cnt])
+        if self._metrics_lag() and pack.is_cuda:
+            stats = self._lagged_stats(pack)  # the previous round's numbers: the host never waits for this round
+        else:
+            stats = pack.tolist()  # the round's single host sync
         results = {"train_loss": stats[0] / stats[1] if stats[1] > 0 else float("nan")}
+        if self._metrics_lag() and pack.is_cuda:
+            results["train_loss_lag"] = 1
         results.update(server_return)
         results["timers"] = T.snapshot()
         results["timers"].update({k: v for k, v in self.engine.timers.items()})
@@ -266,6 +272,42 @@ class Fedavg(Algorithm):
         if info and "num_selected" in info:
             results["num_selected_clients"] = int(info["num_selected"])
         return results
+
+    # -- deferred loss read-back (BLADES_METRICS_LAG=1) ---------------------------------------------------------
+    # Reading the round's loss is the one host sync of a round: the host then starts the next round's launches on an
+    # idle GPU.  On 0.6-3 ms rounds (60 clients, MLP / CNN) that bubble is 0.15-0.2 ms per round (timeline:
+    # profiles/r3_small_round_timeline_mlp.txt).  With the switch on, ``train()`` reports the loss of the PREVIOUS
+    # round (``train_loss_lag: 1`` in the result row; NaN in the first row) from a pinned buffer whose copy finished a
+    # round ago, the host runs at most one round ahead of the GPU, and ``flush_metrics()`` returns the last round's
+    # loss.  Off by default: the reference's rows carry their own round's loss.
+    def _metrics_lag(self) -> bool:
+        import os
+
+        return os.environ.get("BLADES_METRICS_LAG", "0") == "1"
+
+    def _lagged_stats(self, pack):
+        st = self.__dict__.setdefault("_lag", {"slots": None, "i": 0, "prev": None})
+        if st["slots"] is None:
+            st["slots"] = [(torch.zeros(2, dtype=pack.dtype).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+        buf, ev = st["slots"][st["i"]]
+        st["i"] ^= 1
+        buf.copy_(pack, non_blocking=True)
+        ev.record()
+        prev, st["prev"] = st["prev"], (buf, ev)
+        if prev is None:
+            return [float("nan"), 0.0]
+        prev[1].synchronize()
+        return prev[0].tolist()
+
+    def flush_metrics(self):
+        """Loss of the last trained round when losses are read back one round late (else None)."""
+        st = self.__dict__.get("_lag")
+        if not st or st["prev"] is None:
+            return None
+        buf, ev = st["prev"]
+        ev.synchronize()
+        s, c = buf.tolist()
+        return s / c if c > 0 else float("nan")
 
     def _check_replicas(self):
         """"allgather" layout: every rank aggregates the full matrix on its own and steps its own copy of theta, so

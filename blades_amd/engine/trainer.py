@@ -445,8 +445,11 @@ class ClientEngine:
                     X = tf.apply(X, params)
                 if any_flip:
                     Y = torch.where(flip.unsqueeze(1) > 0, flip.unsqueeze(1) - 1 - Y, Y)
-                return self.fused.run(X, Y, block, scale)
+                losses = self.fused.run(X, Y, block, scale)
+                # the round's loss bookkeeping for this chunk rides in the graph (four eager launches otherwise)
+                return losses, (losses.double() * benign).sum(), benign.sum()
 
+            benign = self._chunk_consts(rows)[1]
             g = torch.cuda.CUDAGraph()
             try:
                 # Every chunk graph has a memory pool of its own (torch's default).  Round 1 saw sporadic
@@ -461,7 +464,7 @@ class ClientEngine:
                 if os.environ.get("BLADES_GRAPH_SHARED_POOL") == "1":  # diagnostics (tools/probes/poison_probe.py)
                     pool = self.__dict__.setdefault("_graph_pool", torch.cuda.graph_pool_handle())
                 with torch.cuda.graph(g, pool=pool):
-                    losses = body()
+                    losses, loss_part, cnt_part = body()
             except Exception as e:  # noqa: BLE001 — anything not capturable: stay eager for good
                 self._graph_failed = True
                 self._graph_error = repr(e)
@@ -469,7 +472,8 @@ class ClientEngine:
                 torch.cuda.synchronize()
                 return None
             # everything the graph reads by address must outlive it: keep the per-chunk tensors with the graph
-            ent.update(graph=g, losses=losses, params=params, keep=(scale, flip, gscale, block, dev_rows))
+            ent.update(graph=g, losses=losses, params=params, keep=(scale, flip, gscale, block, dev_rows, benign),
+                       loss_pair=(loss_part, cnt_part))
         self.sampler.prepare(srows)
         self.drop_ctx.set_tag(self._drop_tag())
         if aug:
@@ -480,6 +484,7 @@ class ClientEngine:
         ent["graph"].replay()
         self.graph_replays += 1
         self.sampler.finish(srows)
+        self._graph_loss_pair = ent["loss_pair"]
         return ent["losses"]
 
     def _train_chunk_fedsgd(self, theta, rows, srows):
@@ -770,8 +775,11 @@ class ClientEngine:
                         losses = self._train_chunk_fedsgd(theta, rows, ks)
                     else:
                         losses = self._train_chunk_general(theta, rows, ks)
-                    benign = self._chunk_consts(rows)[1]
-                    pending.append(((losses.double() * benign).sum(), benign.sum()))
+                    pair = self.__dict__.pop("_graph_loss_pair", None)  # (a replayed chunk graph computed it)
+                    if pair is None:
+                        benign = self._chunk_consts(rows)[1]
+                        pair = ((losses.double() * benign).sum(), benign.sum())
+                    pending.append(pair)
                     if st is not None and early:
                         done.append(st.record_event())
                 if not early:
