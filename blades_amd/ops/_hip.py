@@ -297,6 +297,8 @@ def _row_reduce_call(U, kind, m=None, valid_cols=None, counts=False):
     dev = U.device
     m = _vec(m, Dl, dev, name="m")
     nch = _row_chunks(Dl)
+    if nch > 65535:  # (grid.y of the row kernels; 2^29 columns per rank)
+        raise ValueError("row reductions: more than 2^29 columns per rank")
     part = _empty(K * nch, device=dev)
     cpart = _empty(K * nch * 3, device=dev, dtype=torch.int32) if counts else None
     out = _empty(K, device=dev)
